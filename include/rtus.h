@@ -1,0 +1,155 @@
+/*
+ * rtus.h — C ABI of librtus.so, the MI355X (gfx950) travel-time ray tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of edudscrc/ray-tracing-ultrasound: the
+ * ray-tracing loop of main_rt.py (shoot_rays + element matcher) and the element x focal-point
+ * travel-time solves built on it.  The reference has no FFI of its own — its boundary is the
+ * Python function shoot_rays(x_a, z_a, z_f, alpha, plot) -> dict of 8 float64[N]
+ * (main_rt.py:337, 432-441) plus module globals (main_rt.py:449-467).  Every entry point below
+ * names the reference lines it replaces; INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; all functions return 0 (RTUS_OK) or a
+ *     negative rtus_status; nothing throws; no global mutable state; re-entrant per (device, stream).
+ *   - all real data is float64 unless the name ends in _f32.
+ *   - "*_dev" entry points take DEVICE pointers and a hipStream_t (passed as void*), launch
+ *     asynchronously and never allocate or synchronise.  The un-suffixed twins take HOST
+ *     buffers, stage them through HBM on `device`, run the same kernels and synchronise.
+ *   - invalid rays are NaN (never sentinels), exactly as the reference's consumers expect
+ *     (main_compare.py:531-534, main_rt.py:495).
+ */
+#ifndef RTUS_H
+#define RTUS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTUS_VERSION 100 /* 0.1.0 */
+
+typedef enum rtus_status {
+    RTUS_OK = 0,
+    RTUS_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad flag (reference: ValueError main_rt.py:24-29) */
+    RTUS_ERR_NO_DEVICE = -2,     /* no HIP device / device index out of range */
+    RTUS_ERR_HIP = -3,           /* a HIP runtime call failed; rtus_last_hip_error() has the code */
+    RTUS_ERR_WORKSPACE = -4,     /* workspace pointer null or too small */
+    RTUS_ERR_UNSUPPORTED = -5    /* e.g. more layers than RTUS_MAX_LAYERS */
+} rtus_status;
+
+/*
+ * Acoustic-lens constants.  Replaces the module globals c1, c2, l0, h0, d that the reference's
+ * helpers read implicitly (main_rt.py:181-201; set at main_rt.py:449-455).
+ */
+typedef struct rtus_lens {
+    double c1; /* speed in the lens   [m/s]  main_rt.py:449 */
+    double c2; /* speed in the water  [m/s]  main_rt.py:450 */
+    double l0; /* lens design length  [m]    main_rt.py:453 */
+    double h0; /* lens design height  [m]    main_rt.py:454 */
+    double d;  /* array plane z = l0+h0 [m]  main_rt.py:455 */
+} rtus_lens;
+
+/* Slots of the 8-array result of shoot_rays (main_rt.py:432-441), in this order. */
+enum {
+    RTUS_LENS_1_X = 0, RTUS_LENS_1_Z = 1, RTUS_PIPE_X = 2, RTUS_PIPE_Z = 3,
+    RTUS_LENS_2_X = 4, RTUS_LENS_2_Z = 5, RTUS_TARGET_X = 6, RTUS_TARGET_Z = 7
+};
+
+/* Per-ray status bits (optional output). */
+#define RTUS_RAY_REF_RAISES 0x1u /* pipe point is NaN: the reference raises LinAlgError here (np.polyfit, main_rt.py:73); we return NaN */
+
+const char *rtus_strerror(int status);
+int rtus_version(void);
+int rtus_last_hip_error(void);
+int rtus_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * Forward trace — replaces shoot_rays (main_rt.py:337-405, 432-441) and its helpers
+ * h_from_alpha/dh_from_alpha/x_z_from_alpha/dz_dx_from_alpha (:180-234), refraction/reflection
+ * (:267-292), dzdx_pipe (:237-238), roots_bhaskara (:171-177) and the per-ray
+ * find_line_curve_intersection loop (:6-168, :384-393), batched over n_geom pipe geometries
+ * and n_tx transmit points.  Segment times replace dist + the TOF sums (main_rt.py:444-445,
+ * 497-500; main_compare.py:514-517).
+ *
+ *   geoms   [n_geom][2]  (r_outer, pipe_offset)           main_rt.py:466-467
+ *   x_a,z_a [n_tx]       transmit points                  main_rt.py:482
+ *   alpha   [n_rays]     launch-angle grid; ALSO defines the lens polyline the reflected line is
+ *                        intersected with (main_rt.py:338, 390)
+ *   z_f     [n_rays]     landing plane per ray            main_rt.py:404
+ *   out8    [n_geom][n_tx][8][n_rays]   nullable          main_rt.py:432-441
+ *   tof4    [n_geom][n_tx][4][n_rays]   nullable          main_compare.py:514-517
+ *   tof     [n_geom][n_tx][n_rays]      nullable  ((t1+t2)+t3)+t4, order of main_rt.py:497-500
+ *   land_x  [n_geom][n_tx][n_rays]      nullable  (= out8 slot RTUS_TARGET_X alone)
+ *   status  [n_geom][n_tx][n_rays]      nullable  RTUS_RAY_* bits
+ * ---------------------------------------------------------------------------------------- */
+size_t rtus_shoot_workspace_bytes(int n_rays);
+
+int rtus_shoot_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,
+                   const double *d_x_a, const double *d_z_a, int n_tx,
+                   const double *d_alpha, const double *d_z_f, int n_rays,
+                   double *d_out8, double *d_tof4, double *d_tof, double *d_land_x,
+                   uint8_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream);
+
+int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
+               const double *x_a, const double *z_a, int n_tx,
+               const double *alpha, const double *z_f, int n_rays,
+               double *out8, double *tof4, double *tof, double *land_x, uint8_t *status,
+               int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Element matcher — replaces the scan of main_rt.py:487-501: for each receive element the FIRST
+ * ray (ascending index) with np.isclose(land_x[ray], x_rx[e], rtol, atol), i.e.
+ * |land_x - x_rx| <= atol + rtol*|x_rx| (NaN never matches).  n_batch = n_geom*n_tx rows.
+ *
+ *   land_x, tof [n_batch][n_rays]    (outputs of rtus_shoot*)
+ *   x_rx        [n_rx]
+ *   first_ray   [n_batch][n_rx] int32, -1 when no ray hits   (also the kernel's scratch)
+ *   hit         [n_batch][n_rx] uint8  nullable               main_rt.py:496
+ *   tof_hit     [n_batch][n_rx]        nullable, 0.0 if none  main_rt.py:493, 497-500
+ * rtus_ray_hits: per ray, does ANY element match (main_compare.py:518-521).
+ * ---------------------------------------------------------------------------------------- */
+int rtus_match_dev(const double *d_land_x, const double *d_tof, int n_batch, int n_rays,
+                   const double *d_x_rx, int n_rx, double atol, double rtol,
+                   int32_t *d_first_ray, uint8_t *d_hit, double *d_tof_hit, void *stream);
+
+int rtus_match(const double *land_x, const double *tof, int n_batch, int n_rays,
+               const double *x_rx, int n_rx, double atol, double rtol,
+               int32_t *first_ray, uint8_t *hit, double *tof_hit, int device);
+
+int rtus_ray_hits_dev(const double *d_land_x, int n_batch, int n_rays, const double *d_x_rx,
+                      int n_rx, double atol, double rtol, uint8_t *d_ray_hit, void *stream);
+
+int rtus_ray_hits(const double *land_x, int n_batch, int n_rays, const double *x_rx, int n_rx,
+                  double atol, double rtol, uint8_t *ray_hit, int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Element x focal-point Fermat travel times through horizontal layers (BASELINE configs 2, 3, 5).
+ * NOT IN THE REFERENCE (it has no planar interfaces) — the build's own solver, "parity
+ * unpinned"; it replaces nothing in main_rt.py and is checked against oracle/ + closed forms.
+ *
+ *   z_if [n_if]    interface depths, strictly ascending (host memory, copied into kernel args)
+ *   c    [n_if+1]  speeds; c[i] applies between interface i-1 and interface i
+ *   xe,ze [n_e]    sources (elements), ze < z_if[0]
+ *   xf,zf [n_f]    targets (focal points), zf > ze; the path stops in whichever layer holds zf
+ *   tt   [n_e][n_f] travel times [s]; NaN where zf <= ze
+ *   iters [n_e][n_f] uint8 nullable: Newton iterations used (diagnostic)
+ * rtus_tt_layers_f32 computes in fp32 (BASELINE config 4's dtype), same layout with floats.
+ * ---------------------------------------------------------------------------------------- */
+#define RTUS_MAX_LAYERS 8
+
+int rtus_tt_layers_dev(const double *z_if, const double *c, int n_if,
+                       const double *d_xe, const double *d_ze, int n_e,
+                       const double *d_xf, const double *d_zf, int n_f,
+                       double *d_tt, uint8_t *d_iters, void *stream);
+
+int rtus_tt_layers(const double *z_if, const double *c, int n_if,
+                   const double *xe, const double *ze, int n_e,
+                   const double *xf, const double *zf, int n_f,
+                   double *tt, uint8_t *iters, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTUS_H */

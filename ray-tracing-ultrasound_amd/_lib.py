@@ -1,0 +1,94 @@
+"""ctypes loader for librtus.so (the C ABI in include/rtus.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded this module raises,
+loudly.  ``oracle/`` is never imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtus.so")
+CSRC = os.path.join(HERE, "csrc")
+
+_lib = None
+
+
+class RtusError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(f"{what}: rtus status {status} ({_strerror(status)})")
+
+
+class Lens(C.Structure):
+    """rtus_lens — replaces the reference's module globals c1, c2, l0, h0, d (main_rt.py:449-455)."""
+    _fields_ = [("c1", C.c_double), ("c2", C.c_double), ("l0", C.c_double), ("h0", C.c_double),
+                ("d", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile librtus.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _strerror(status):
+    try:
+        return lib().rtus_strerror(int(status)).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def lib():
+    """Load librtus.so once; declare every prototype of include/rtus.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ray-tracing-ultrasound_amd/csrc`. There is no CPU fallback.")
+    # PyTorch bundles its own libamdhip64.so.7; load it first so that one HIP runtime serves both
+    # torch tensors and librtus streams/pointers in this process.
+    if "torch" not in sys.modules and os.environ.get("RTUS_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
+    L.rtus_strerror.argtypes = [ip]
+    L.rtus_strerror.restype = C.c_char_p
+    L.rtus_version.restype = ip
+    L.rtus_last_hip_error.restype = ip
+    L.rtus_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.rtus_shoot_workspace_bytes.argtypes = [ip]
+    L.rtus_shoot_workspace_bytes.restype = C.c_size_t
+    LP = C.POINTER(Lens)
+    L.rtus_shoot_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, vp, C.c_size_t, vp]
+    L.rtus_shoot.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, ip]
+    L.rtus_match_dev.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, vp]
+    L.rtus_match.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, ip]
+    L.rtus_ray_hits_dev.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp]
+    L.rtus_ray_hits.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, ip]
+    L.rtus_tt_layers_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, vp]
+    L.rtus_tt_layers.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, ip]
+    for name in ("rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match", "rtus_ray_hits_dev",
+                 "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_device_count"):
+        getattr(L, name).restype = ip
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        raise RtusError(status, what)
+
+
+EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count",
+           "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
+           "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers")

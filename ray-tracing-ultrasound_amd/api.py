@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's call surface, on top of the C ABI (include/rtus.h).
+
+``shoot_rays(x_a, z_a, z_f, alpha, plot=False)`` keeps the positional signature and the 8-key
+dict of float64[N] of the reference (main_rt.py:337, 432-441).  The constants the reference
+reads as module globals (c1, c2, l0, h0, d, r_outer, pipe_offset — main_rt.py:449-467) are an
+explicit :class:`Params`; when none is given they are looked up the way the reference's scripts
+define them (``configure(...)`` first, then same-named attributes of ``__main__``).
+
+Everything here runs on the GPU through librtus.so.  There is no CPU fallback.
+"""
+import ctypes as C
+import sys
+import warnings
+from dataclasses import dataclass, replace
+
+import numpy as np
+
+from . import _lib
+from ._lib import Lens
+
+KEYS = ("lens_1_x", "lens_1_z", "pipe_x", "pipe_z", "lens_2_x", "lens_2_z", "target_x", "target_z")
+
+
+@dataclass(frozen=True)
+class Params:
+    """Medium + geometry constants (reference: module globals, main_rt.py:449-467)."""
+    c1: float = 6400.0                     # main_rt.py:449
+    c2: float = 1483.0                     # main_rt.py:450
+    l0: float = 0.12156646438729327        # main_rt.py:453
+    h0: float = 0.08843353561270673        # main_rt.py:454
+    d: float = None                        # main_rt.py:455 (l0 + h0 when None)
+    r_outer: float = 0.05                  # main_rt.py:466
+    pipe_offset: float = 0.0               # main_rt.py:467
+
+    def __post_init__(self):
+        if self.d is None:
+            object.__setattr__(self, "d", float(np.float64(self.l0) + np.float64(self.h0)))
+
+    def lens(self) -> Lens:
+        return Lens(float(self.c1), float(self.c2), float(self.l0), float(self.h0), float(self.d))
+
+
+#: the reference's launch-angle half-aperture (main_rt.py:457)
+ALPHA_MAX = float(np.float64(50.62033040986099 * (np.pi / 180)))
+
+_configured = None
+
+
+def configure(params: Params = None, **kw) -> Params:
+    """Set the default Params (the explicit replacement for assigning module globals)."""
+    global _configured
+    base = params if params is not None else (_configured or Params())
+    _configured = replace(base, **kw) if kw else base
+    return _configured
+
+
+def _resolve(params):
+    if params is not None:
+        return params
+    if _configured is not None:
+        return _configured
+    main = sys.modules.get("__main__")
+    names = ("c1", "c2", "l0", "h0", "d", "r_outer", "pipe_offset")
+    if main is not None and all(hasattr(main, n) for n in names):   # main_compare.py-style script
+        return Params(**{n: float(getattr(main, n)) for n in names})
+    raise ValueError("no Params given: pass params=..., call configure(...), or define "
+                     "c1,c2,l0,h0,d,r_outer,pipe_offset in __main__ as the reference scripts do")
+
+
+def reference_elements(num_elements=64, pitch=0.0006):
+    """main_rt.py:469-474 — centred linear array plus the virtual centre element at index 32."""
+    x_a = np.arange(num_elements, dtype=np.float64) * np.float64(pitch)
+    x_a = x_a - np.mean(x_a)
+    return np.insert(x_a, num_elements // 2, np.float64(0.0))
+
+
+def _f64(a, name, ndim=1):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim == 1:
+        a = np.atleast_1d(a)
+    if a.ndim != ndim:
+        raise ValueError(f"{name} must be {ndim}-D, got shape {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want=("out8",), device=0):
+    """Forward trace for n_geom geometries x n_tx transmit points in ONE launch.
+
+    geoms: [n_geom, 2] of (r_outer, pipe_offset); default = the one geometry in ``params``.
+    want:  any of "out8" [G,T,8,N], "tof4" [G,T,4,N], "tof" [G,T,N], "land_x" [G,T,N], "status".
+    """
+    p = _resolve(params)
+    x_a, z_a = _f64(x_a, "x_a"), _f64(z_a, "z_a")
+    alpha, z_f = _f64(alpha, "alpha"), _f64(z_f, "z_f")
+    if x_a.shape != z_a.shape:
+        raise ValueError("x_a and z_a must have the same length")        # main_rt.py:28-29
+    if alpha.shape != z_f.shape:
+        raise ValueError("alpha and z_f must have the same length")
+    if alpha.size < 2:
+        raise ValueError("Curve needs at least two points.")             # main_rt.py:26-27
+    geoms = (np.asarray([[p.r_outer, p.pipe_offset]], dtype=np.float64) if geoms is None
+             else _f64(geoms, "geoms", 2))
+    if geoms.shape[1] != 2:
+        raise ValueError("geoms must be [n_geom, 2] = (r_outer, pipe_offset)")
+    G, T, N = geoms.shape[0], x_a.size, alpha.size
+    bufs = dict(out8=None, tof4=None, tof=None, land_x=None, status=None)
+    shapes = dict(out8=(G, T, 8, N), tof4=(G, T, 4, N), tof=(G, T, N), land_x=(G, T, N), status=(G, T, N))
+    for w in want:
+        if w not in bufs:
+            raise ValueError(f"unknown output {w!r}")
+        bufs[w] = np.empty(shapes[w], dtype=np.uint8 if w == "status" else np.float64)
+    lens = p.lens()
+    st = _lib.lib().rtus_shoot(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), _ptr(z_f), N,
+                               _ptr(bufs["out8"]), _ptr(bufs["tof4"]), _ptr(bufs["tof"]), _ptr(bufs["land_x"]),
+                               _ptr(bufs["status"]), int(device))
+    _lib.check(st, "rtus_shoot")
+    return {w: bufs[w] for w in want}
+
+
+def shoot_rays(x_a, z_a, z_f, alpha, plot=False, *, params: Params = None, device=0):
+    """Drop-in for the reference's shoot_rays (main_rt.py:337): one transmit point, one geometry.
+
+    Returns the same dict of eight float64[N] arrays (main_rt.py:432-441); invalid rays are NaN.
+    ``plot`` is accepted for signature compatibility; plotting (main_rt.py:407-430) is out of scope
+    and the default is False so the call never blocks on a GUI.
+    """
+    if plot:
+        warnings.warn("rtus.shoot_rays: plotting is not part of the accelerated path; ignoring plot=True",
+                      stacklevel=2)
+    if np.ndim(x_a) != 0 or np.ndim(z_a) != 0:
+        raise ValueError("x_a and z_a are scalars (one transmit point), as in main_rt.py:482")
+    out8 = shoot_batch([x_a], [z_a], z_f, alpha, params=params, device=device)["out8"][0, 0]
+    return {k: out8[i].copy() for i, k in enumerate(KEYS)}
+
+
+def match_elements(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, *, device=0):
+    """Element matcher (main_rt.py:487-501): per receive element the first ray within np.isclose.
+
+    land_x, tof: [..., N]; x_rx: [E].  Returns (hit bool[..., E], tof_hit f64[..., E] (0.0 if none),
+    first_ray int32[..., E] (-1 if none)).
+    """
+    land_x = np.ascontiguousarray(land_x, dtype=np.float64)
+    tof = np.ascontiguousarray(tof, dtype=np.float64)
+    if land_x.shape != tof.shape or land_x.ndim < 1:
+        raise ValueError("land_x and tof must have the same shape [..., n_rays]")
+    x_rx = _f64(x_rx, "x_rx")
+    lead, N, E = land_x.shape[:-1], land_x.shape[-1], x_rx.size
+    nb = int(np.prod(lead)) if lead else 1
+    first = np.empty((nb, E), dtype=np.int32)
+    hit = np.empty((nb, E), dtype=np.uint8)
+    tof_hit = np.empty((nb, E), dtype=np.float64)
+    st = _lib.lib().rtus_match(_ptr(land_x), _ptr(tof), nb, N, _ptr(x_rx), E, float(atol), float(rtol),
+                               _ptr(first), _ptr(hit), _ptr(tof_hit), int(device))
+    _lib.check(st, "rtus_match")
+    return (hit.astype(bool).reshape(lead + (E,)), tof_hit.reshape(lead + (E,)), first.reshape(lead + (E,)))
+
+
+def ray_hits(land_x, x_rx, atol=1e-4, rtol=1e-5, *, device=0):
+    """Per ray: does any element match (main_compare.py:518-521)."""
+    land_x = np.ascontiguousarray(land_x, dtype=np.float64)
+    x_rx = _f64(x_rx, "x_rx")
+    lead, N = land_x.shape[:-1], land_x.shape[-1]
+    nb = int(np.prod(lead)) if lead else 1
+    rh = np.empty((nb, N), dtype=np.uint8)
+    st = _lib.lib().rtus_ray_hits(_ptr(land_x), nb, N, _ptr(x_rx), x_rx.size, float(atol), float(rtol),
+                                  _ptr(rh), int(device))
+    _lib.check(st, "rtus_ray_hits")
+    return rh.astype(bool).reshape(lead + (N,))
+
+
+def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, device=0):
+    """Element x focal-point Fermat travel times through horizontal layers -> tt[n_e, n_f].
+
+    NOT in the reference (no planar interfaces there): parity unpinned, see DESIGN.md.
+    """
+    z_if = _f64(z_if, "z_if") if np.size(z_if) else np.zeros(0)
+    c = _f64(c, "c")
+    if c.size != z_if.size + 1:
+        raise ValueError("need len(c) == len(z_if) + 1")
+    xe, ze, xf, zf = _f64(xe, "xe"), _f64(ze, "ze"), _f64(xf, "xf"), _f64(zf, "zf")
+    if xe.shape != ze.shape or xf.shape != zf.shape:
+        raise ValueError("xe/ze and xf/zf must pair up")
+    tt = np.empty((xe.size, xf.size), dtype=np.float64)
+    iters = np.empty((xe.size, xf.size), dtype=np.uint8) if return_iters else None
+    st = _lib.lib().rtus_tt_layers(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze),
+                                   xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), int(device))
+    _lib.check(st, "rtus_tt_layers")
+    return (tt, iters) if return_iters else tt

@@ -1,0 +1,87 @@
+"""Device-resident calls: torch tensors in HBM -> the ``*_dev`` entry points of include/rtus.h.
+
+PyTorch is only plumbing here (device memory + the current HIP stream); every kernel is
+librtus.so's.  All calls are asynchronous on ``torch.cuda.current_stream()``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .api import Params, _resolve
+
+
+def _chk(t, name, dtype=torch.float64):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous CUDA tensor of {dtype}")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ShootPlan:
+    """Pre-allocated workspace + outputs for repeated forward traces of one shape (no allocation,
+    no sync inside ``run`` — safe to capture in a hipGraph)."""
+
+    def __init__(self, n_geom, n_tx, n_rays, *, want=("out8",), params: Params = None, device="cuda"):
+        self.p = _resolve(params)
+        self.G, self.T, self.N = int(n_geom), int(n_tx), int(n_rays)
+        self.ws_bytes = int(_lib.lib().rtus_shoot_workspace_bytes(self.N))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        G, T, N = self.G, self.T, self.N
+        shapes = dict(out8=(G, T, 8, N), tof4=(G, T, 4, N), tof=(G, T, N), land_x=(G, T, N), status=(G, T, N))
+        self.out = {w: torch.empty(shapes[w], dtype=torch.uint8 if w == "status" else torch.float64, device=device)
+                    for w in want}
+        self.lens = self.p.lens()
+
+    def run(self, geoms, x_a, z_a, alpha, z_f):
+        _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(z_f, "z_f")
+        if geoms.shape != (self.G, 2) or x_a.numel() != self.T or z_a.numel() != self.T \
+                or alpha.numel() != self.N or z_f.numel() != self.N:
+            raise ValueError("tensor shapes do not match the plan")
+        o = self.out
+        st = _lib.lib().rtus_shoot_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha),
+                                       _p(z_f), self.N, _p(o.get("out8")), _p(o.get("tof4")), _p(o.get("tof")),
+                                       _p(o.get("land_x")), _p(o.get("status")), _p(self.ws), self.ws_bytes,
+                                       _stream())
+        _lib.check(st, "rtus_shoot_dev")
+        return o
+
+
+def match_dev(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, out=None):
+    """land_x/tof [rows, N], x_rx [E] -> (first_ray i32[rows,E], hit u8[rows,E], tof_hit f64[rows,E])."""
+    _chk(land_x, "land_x"); _chk(tof, "tof"); _chk(x_rx, "x_rx")
+    rows, N, E = land_x.shape[0], land_x.shape[1], x_rx.numel()
+    if out is None:
+        out = (torch.empty((rows, E), dtype=torch.int32, device=land_x.device),
+               torch.empty((rows, E), dtype=torch.uint8, device=land_x.device),
+               torch.empty((rows, E), dtype=torch.float64, device=land_x.device))
+    first, hit, tof_hit = out
+    st = _lib.lib().rtus_match_dev(_p(land_x), _p(tof), rows, N, _p(x_rx), E, float(atol), float(rtol), _p(first),
+                                   _p(hit), _p(tof_hit), _stream())
+    _lib.check(st, "rtus_match_dev")
+    return out
+
+
+def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
+    """Fermat travel times through horizontal layers; z_if/c are small HOST sequences."""
+    import numpy as np
+    z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+    _chk(xe, "xe"); _chk(ze, "ze"); _chk(xf, "xf"); _chk(zf, "zf")
+    n_e, n_f = xe.numel(), xf.numel()
+    if out is None:
+        out = torch.empty((n_e, n_f), dtype=torch.float64, device=xe.device)
+    _chk(out, "out")
+    if out.numel() != n_e * n_f:
+        raise ValueError("out has the wrong size")
+    st = _lib.lib().rtus_tt_layers_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
+                                       _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
+    _lib.check(st, "rtus_tt_layers_dev")
+    return out
