@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (element x focal-point travel-time solves per second) on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+the default workload is BASELINE.json configs[1] — 128-element linear array, 1 planar
+interface, 128x128 focal grid, fp64 — i.e. 2,097,152 Fermat travel-time solves per step per GPU
+(rtus_tt_layers_dev, csrc/rtus_fermat.hip).  With --gpus N > 1 (launched by torch.distributed.run,
+one rank per GPU) every rank solves its own 128-element block of a 128*N-element aperture
+(weak scaling) and the [128*N, 16384] travel-time matrix is reassembled on every rank by an RCCL
+all-gather that overlaps the next step's kernel.
+
+Other workloads (--workload): ref_sweep (the reference's own sweep, main_rt.py:464-501: 210
+geometries x 905 rays forward trace + 65-element matcher), ref_scale (reference geometry,
+1024 tx x 8192 rays), cfg3_planar (256 elements, 2 interfaces, 512x512 grid).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as
+the contract asks (8 B written per solve) — and says which bound actually binds (fp64 VALU).
+`cpu_baseline` is the oracle's fp64 CPU port timed on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2_planar",
+                    choices=["cfg2_planar", "cfg3_planar", "ref_sweep", "ref_scale"])
+    ap.add_argument("--gather", default="on", choices=["on", "off"], help="RCCL all-gather when --gpus > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the reference-path side measurements")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------ workloads
+def planar_inputs(cfg, rank, world):
+    """cfg2 = 128 elems @0.6 mm on z=0, interface z=20 mm, c=(2330,1483), 128x128
+    focal grid over x in [-20,20] mm, z in [25,65] mm; cfg3 = 256 elems @0.3 mm, interfaces at
+    10/25 mm, c=(2330,1483,5900), 512x512 grid.  Rank r owns elements [r*n_e, (r+1)*n_e) of a
+    world*n_e-element aperture (weak scaling)."""
+    if cfg == "cfg2_planar":
+        n_e, pitch, z_if, c, g, zr = 128, 0.6e-3, [0.020], [2330.0, 1483.0], 128, (0.025, 0.065)
+    else:
+        n_e, pitch, z_if, c, g, zr = 256, 0.3e-3, [0.010, 0.025], [2330.0, 1483.0, 5900.0], 512, (0.026, 0.066)
+    n_all = n_e * world
+    x_all = (np.arange(n_all) - (n_all - 1) / 2.0) * pitch
+    xe = x_all[rank * n_e:(rank + 1) * n_e]
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, g), np.linspace(zr[0], zr[1], g))
+    return dict(z_if=z_if, c=c, xe=xe, ze=np.zeros(n_e), xf=xs.ravel(), zf=zs.ravel(), n_e=n_e, n_f=g * g)
+
+
+def ref_inputs(kind):
+    import rtus
+    d = rtus.Params().d
+    if kind == "ref_sweep":          # main_rt.py:464-482
+        n = 905
+        geoms = np.array([[r * 1e-2, o * 1e-3] for r in range(1, 11) for o in range(-10, 11)])
+        xa = np.array([0.0])
+    else:                            # reference geometry scaled up (SURVEY 8(d) row "R")
+        n = 8192
+        geoms = np.array([[0.037, 0.0038]])
+        xa = (np.arange(1024) - 511.5) * 0.3e-3
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    return dict(n=n, geoms=geoms, xa=xa, za=np.full(xa.size, d), alpha=alpha, zf=np.full(n, d),
+                x_rx=rtus.reference_elements())
+
+
+# ------------------------------------------------------------------------------------ main
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import rtus
+    from importlib import import_module
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    wl = args.workload
+    gather = world > 1 and args.gather == "on"
+    works = []
+
+    if wl in ("cfg2_planar", "cfg3_planar"):
+        W = planar_inputs(wl, rank, world)
+        xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
+        n_e, n_f = W["n_e"], W["n_f"]
+        # double-buffered full matrix; each rank's kernel writes straight into its row block
+        full = [torch.empty((world * n_e, n_f), dtype=torch.float64, device=dev) for _ in range(2 if gather else 1)]
+        shard = [f[rank * n_e:(rank + 1) * n_e] for f in full]
+        units_per_step = n_e * n_f
+        alg_bytes = units_per_step * 8 + (2 * n_e + 2 * n_f) * 8
+        kernel = f"rtus_tt_layers_kernel<{len(W['c'])}>"
+
+        def step(s):
+            b = s % len(full)
+            if gather and len(works) >= 2:
+                works[-2].wait()            # the slot's previous all-gather must be done before rewriting it
+            dev_api.tt_layers_dev(W["z_if"], W["c"], xe, ze, xf, zf, out=shard[b])
+            if gather:
+                works.append(dist.all_gather_into_tensor(full[b], shard[b], async_op=True))
+    else:
+        R = ref_inputs(wl)
+        G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
+        plan = dev_api.ShootPlan(G, T, N, want=("tof", "land_x"), params=rtus.Params(), device=dev)
+        geoms, xa, za, alpha, zf = t64(R["geoms"]), t64(R["xa"]), t64(R["za"]), t64(R["alpha"]), t64(R["zf"])
+        x_rx = t64(R["x_rx"])
+        mout = None
+        units_per_step = G * T * N
+        alg_bytes = units_per_step * 16 + N * 16       # tof + land_x written per ray; alpha, z_f read once
+        kernel = "rtus_shoot_kernel"
+
+        def step(s):
+            nonlocal mout
+            o = plan.run(geoms, xa, za, alpha, zf)
+            mout = dev_api.match_dev(o["land_x"].view(G * T, N), o["tof"].view(G * T, N), x_rx, 1e-6, 1e-5, out=mout)
+
+    for s in range(args.warmup):
+        step(s)
+    for w in works:
+        w.wait()
+    works.clear()
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()                      # same (current) stream the library launches on
+    for s in range(args.steps):
+        step(s)
+    ev1.record()
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration over the timed region
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_units = units_per_step * world * args.steps
+    value = total_units / dt / 1e6
+
+    out = {
+        "metric": "Mrays/sec (elem x focal travel-time solves)", "value": round(value, 3), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": {
+            "cfg2_planar": "BASELINE configs[1]: 128-element array, 1 planar interface (z=20 mm, c=2330/1483 m/s), "
+                           "128x128 focal grid, fp64, per GPU",
+            "cfg3_planar": "BASELINE configs[2]: 256-element array, 2 planar interfaces, 512x512 focal grid, fp64, per GPU",
+            "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
+            "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
+            "solves_per_step_per_gpu": units_per_step,
+            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather overlapped" if gather else ""),
+        },
+    }
+    ach = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get(wl)
+        except Exception:
+            traffic = None
+    out["roofline"] = {
+        "bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 5),
+        "note": "scalar fp64 root-find: 8-16 B of HBM traffic per solve, so the HBM fraction is small by "
+                "construction; the binding resource is fp64 VALU issue (see DESIGN.md, profiles/)",
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl)
+    if rank == 0 and world == 1 and not args.no_extra and wl == "cfg2_planar":
+        out["extra"] = extra_ref_path(dev_api, rtus, t64, torch)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl):
+    """Oracle-side CPU port timed on this host (bounded sample of the same workload)."""
+    from oracle import cport
+    cores = cport.num_threads()
+    if wl in ("cfg2_planar", "cfg3_planar"):
+        W = planar_inputs(wl, 0, 1)
+        ne = min(W["n_e"], 32 if wl == "cfg2_planar" else 2)
+        cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:1], W["ze"][:1], W["xf"][:1024], W["zf"][:1024])
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:ne], W["ze"][:ne], W["xf"], W["zf"])
+            reps += 1
+            if time.perf_counter() - t0 > 10.0:
+                break
+        dt = time.perf_counter() - t0
+        v = reps * ne * W["n_f"] / dt / 1e6
+        return {"value": round(v, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x ({ne} elements x {W['n_f']} focal points) of the same workload, "
+                          f"oracle/rt_oracle.c orc_tt_layers_newton (fp64 Newton, OpenMP)"}
+    R = ref_inputs(wl)
+    g = R["geoms"][:: max(1, R["geoms"].shape[0] // 16)][:16]
+    xa = R["xa"][:8]
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        cport.shoot_batch(xa, R["za"][:xa.size], R["zf"], R["alpha"], g)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0:
+            break
+    dt = time.perf_counter() - t0
+    v = reps * g.shape[0] * xa.size * R["n"] / dt / 1e6
+    return {"value": round(v, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x ({g.shape[0]} geometries x {xa.size} tx x {R['n']} rays) forward trace, "
+                      f"oracle/rt_oracle.c orc_shoot_batch (fp64, O(N) polyline scan per ray, OpenMP)"}
+
+
+def extra_ref_path(dev_api, rtus, t64, torch):
+    """Side measurement (not the headline): the reference-parity path on the same GPU."""
+    res = {}
+    for kind in ("ref_sweep", "ref_scale"):
+        R = ref_inputs(kind)
+        G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
+        plan = dev_api.ShootPlan(G, T, N, want=("tof", "land_x"), params=rtus.Params())
+        a = [t64(R[k]) for k in ("geoms", "xa", "za", "alpha", "zf")]
+        x_rx = t64(R["x_rx"])
+        mout = None
+        for _ in range(3):
+            o = plan.run(*a)
+            mout = dev_api.match_dev(o["land_x"].view(G * T, N), o["tof"].view(G * T, N), x_rx, out=mout)
+        torch.cuda.synchronize()
+        k = 20 if kind == "ref_sweep" else 5
+        t0 = time.perf_counter()
+        for _ in range(k):
+            o = plan.run(*a)
+            mout = dev_api.match_dev(o["land_x"].view(G * T, N), o["tof"].view(G * T, N), x_rx, out=mout)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        res[kind] = {"Mrays_per_s": round(G * T * N / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4),
+                     "rays_per_pass": G * T * N}
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,8 @@ def lib():
         L.orc_shoot_batch.restype = None
         L.orc_tt_layers.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_tt_layers.restype = None
+        L.orc_tt_layers_newton.argtypes = L.orc_tt_layers.argtypes
+        L.orc_tt_layers_newton.restype = None
         L.orc_lens_point.argtypes = [C.POINTER(_Lens), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lens_point.restype = None
         L.orc_num_threads.restype = C.c_int
@@ -107,6 +109,14 @@ def tt_layers(z_if, c, xe, ze, xf, zf):
     z_if, c, xe, ze, xf, zf = map(_f64, (z_if, c, xe, ze, xf, zf))
     tt = np.empty((xe.size, xf.size), dtype=np.float64)
     lib().orc_tt_layers(z_if, c, z_if.size, xe, ze, xe.size, xf, zf, xf.size, tt)
+    return tt
+
+
+def tt_layers_newton(z_if, c, xe, ze, xf, zf):
+    """fp64 Newton CPU port of the same solve (bench.py's cpu_baseline leg; OpenMP)."""
+    z_if, c, xe, ze, xf, zf = map(_f64, (z_if, c, xe, ze, xf, zf))
+    tt = np.empty((xe.size, xf.size), dtype=np.float64)
+    lib().orc_tt_layers_newton(z_if, c, z_if.size, xe, ze, xe.size, xf, zf, xf.size, tt)
     return tt
 
 

@@ -1,0 +1,124 @@
+"""CPU: pin the oracle (oracle/rt_oracle.c) to the reference.
+
+Golden vectors = outputs of the reference itself (tests/golden/make_golden.py ran
+main_rt.shoot_rays in the build container) + the reference's own compare.csv / database_2.csv.
+Tolerances: positions 1e-12 m, times 1e-15 s (observed: ~1e-14 m, ~1e-18 s — libm ulps).
+"""
+import csv
+import os
+
+import numpy as np
+
+from conftest import D_PLANE, GOLDEN, load_golden, max_abs, nan_equal_mask
+from oracle import cport
+
+POS_TOL, TIME_TOL = 1e-12, 1e-15
+
+
+def _check8(o, r, tag):
+    for k in range(8):
+        assert nan_equal_mask(o[k], r[k]), f"{tag}: NaN mask differs in slot {k}"
+        assert max_abs(o[k], r[k]) < POS_TOL, f"{tag}: slot {k}"
+
+
+def test_oracle_vs_reference_compare_config():
+    g = load_golden("compare_cfg.npz")
+    o, st = cport.shoot(0.0, D_PLANE, g["zf"], g["alpha"], 0.037, 0.0038)
+    _check8(o, g["out8"], "compare")
+    t4 = cport.tof4(0.0, D_PLANE, o)
+    assert nan_equal_mask(t4, g["tof4"]) and max_abs(t4, g["tof4"]) < TIME_TOL
+    assert st.sum() == 0
+
+
+def test_oracle_vs_compare_csv():
+    """The reference's own output file (main_compare.py:502-524): alpha, 4 segment times, hitted."""
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "compare.csv"))))
+    assert rows[0] == ["alpha", "offset", "radius", "hitted", "tof_1", "tof_2", "tof_3", "tof_4"]
+    rows = rows[1:]
+    assert len(rows) == 1810
+    alpha_csv = np.array([float(r[0]) for r in rows])
+    alpha_max = np.float64(50.62033040986099 * (np.pi / 180))
+    alpha = np.linspace(-alpha_max, alpha_max, 1810)
+    assert np.array_equal(alpha, alpha_csv)                       # R11: the grid is bit-exact
+    tofs = np.array([[float(v) for v in r[4:8]] for r in rows]).T
+    hitted = np.array([r[3] == "True" for r in rows])
+    o, _ = cport.shoot(0.0, D_PLANE, np.full(1810, D_PLANE), alpha, 0.037, 0.0038)
+    t4 = cport.tof4(0.0, D_PLANE, o)
+    assert nan_equal_mask(t4, tofs)
+    assert max_abs(t4, tofs) < TIME_TOL
+    x_elem = load_golden("compare_cfg.npz")["x_elem"]
+    assert np.array_equal(cport.ray_hits(o[6], x_elem, 1e-4), hitted)    # main_compare.py:518-521
+    assert hitted.sum() == 393
+
+
+def test_oracle_vs_database2_csv():
+    """The reference's sweep output (main_rt.py:464-504): 10 radii x 21 offsets x 65 elements."""
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "database_2.csv"))))[1:]
+    assert len(rows) == 13650
+    db_hit = np.array([r[3] == "True" for r in rows]).reshape(210, 65)
+    db_tof = np.array([float(r[4]) for r in rows]).reshape(210, 65)
+    s = load_golden("sweep_cfg.npz")
+    alpha, geoms, x_elem = s["alpha"], s["geoms"], s["x_elem"]
+    zf = np.full(905, D_PLANE)
+    out = cport.shoot_batch([0.0], [D_PLANE], zf, alpha, geoms)
+    for gi in range(210):
+        o = out[gi, 0]
+        t4 = cport.tof4(0.0, D_PLANE, o)
+        hit, tof, _ = cport.match(o[6], t4, x_elem, 1e-6)
+        assert np.array_equal(hit, db_hit[gi]), f"geometry {gi}"
+        assert np.max(np.abs(tof - db_tof[gi])) < TIME_TOL
+        ref = s["target_x_tof"][gi]
+        assert nan_equal_mask(o[6], ref[0]) and max_abs(o[6], ref[0]) < 1e-11
+    assert db_hit.sum() == 498
+
+
+def test_oracle_vs_reference_edges_alltx_nesting():
+    e = load_golden("edge_cfg.npz")
+    for tag in ("q1nan", "tir", "off0", "offtx"):
+        r_o, off, x_tx = e[tag + "_cfg"]
+        o, _ = cport.shoot(x_tx, D_PLANE, np.full(905, D_PLANE), e["alpha"], r_o, off)
+        _check8(o, e[tag], tag)
+    assert int(e["miss_raises"]) == 1            # the reference raises on a missed pipe
+    o, st = cport.shoot(0.0, D_PLANE, np.full(905, D_PLANE), e["alpha"], 0.005, 0.05)
+    assert st.any() and np.isnan(o[2][st.astype(bool)]).all() and np.isnan(o[6][st.astype(bool)]).all()
+    for tag in ("a", "b"):
+        g = load_golden(f"alltx_{tag}.npz")
+        for t in range(0, 65, 4):
+            o, _ = cport.shoot(g["x_elem"][t], D_PLANE, np.full(905, D_PLANE), g["alpha"],
+                               float(g["r_outer"]), float(g["pipe_offset"]))
+            _check8(o, g["out8"][t], f"alltx_{tag}[{t}]")
+    n = load_golden("nest_cfg.npz")
+    alpha_max = np.float64(50.62033040986099 * (np.pi / 180))
+    for k in (181, 1809, 3617):
+        o, _ = cport.shoot(0.0, D_PLANE, np.full(k, D_PLANE), np.linspace(-alpha_max, alpha_max, k), 0.037, 0.0038)
+        _check8(o, n[f"n{k}"], f"n{k}")
+
+
+def test_line_curve_corner_cases():
+    """find_line_curve_intersection semantics (main_rt.py:78-168) on hand-made polylines."""
+    import ctypes as C
+    L = cport.lib()
+    L.orc_line_curve.argtypes = [C.c_double, C.c_double, cport._dp, cport._dp, C.c_int,
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_line_curve.restype = C.c_int
+
+    def run(m, b, xc, yc):
+        xi, yi = C.c_double(), C.c_double()
+        ok = L.orc_line_curve(m, b, np.asarray(xc, float), np.asarray(yc, float), len(xc), C.byref(xi), C.byref(yi))
+        return (xi.value, yi.value) if ok else None
+
+    xc = [0.0, 1.0, 2.0, 3.0, 4.0]
+    # two crossings: the earlier INDEX wins (curve dips below the line y=0.5 between 1..3)
+    assert run(0.0, 0.5, xc, [1.0, 0.0, 0.0, 1.0, 1.0]) == (0.5, 0.5)
+    # a curve point exactly on the line counts as a sign change (np.sign(0) = 0) -> segment idx 0
+    assert run(0.0, 0.0, xc, [1.0, 0.0, -1.0, -1.0, -1.0]) == (1.0, 0.0)
+    # no crossing, nothing within isclose -> None
+    assert run(0.0, -1.0, xc, [1.0, 1.0, 1.0, 1.0, 1.0]) is None
+    # no crossing but a point within atol=1e-8 of the line -> that curve point
+    assert run(0.0, 1.0 - 5e-9, xc, [2.0, 1.0, 2.0, 2.0, 2.0]) == (1.0, 1.0)
+    # NaN line -> sign change "found" at 0, then the bounds check fails -> None
+    assert run(float("nan"), 0.0, xc, [1.0, 0.0, -1.0, -1.0, -1.0]) is None
+    # segment parallel to the line within isclose and collinear within isclose -> segment midpoint
+    assert run(1.0, 0.0, [0.0, 1.0, 2.0], [1e-12, 1.0, 3.0]) == (0.5, 0.5)
+    # vertical curve segment (isclose(x1, x2)) uses the line's y at x1 with the +-1e-9 bounds check
+    assert run(1.0, 0.0, [1.0, 1.0, 2.0], [2.0, 0.0, 0.0]) == (1.0, 1.0)
