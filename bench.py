@@ -108,26 +108,29 @@ def main():
     t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
     wl = args.workload
     gather = world > 1 and args.gather == "on"
-    works = []
 
     if wl in ("cfg2_planar", "cfg3_planar"):
         W = planar_inputs(wl, rank, world)
         xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
         n_e, n_f = W["n_e"], W["n_f"]
         # double-buffered full matrix; each rank's kernel writes straight into its row block
-        full = [torch.empty((world * n_e, n_f), dtype=torch.float64, device=dev) for _ in range(2 if gather else 1)]
-        shard = [f[rank * n_e:(rank + 1) * n_e] for f in full]
+        dist_api = import_module("ray-tracing-ultrasound_amd.dist")
+        slots = 2 if gather else 1
+        m = dist_api.RowShardedMatrix(world * n_e, n_f, device=dev, slots=slots)
         units_per_step = n_e * n_f
         alg_bytes = units_per_step * 8 + (2 * n_e + 2 * n_f) * 8
         kernel = f"rtus_tt_layers_kernel<{len(W['c'])}>"
 
         def step(s):
-            b = s % len(full)
-            if gather and len(works) >= 2:
-                works[-2].wait()            # the slot's previous all-gather must be done before rewriting it
-            dev_api.tt_layers_dev(W["z_if"], W["c"], xe, ze, xf, zf, out=shard[b])
+            b = s % slots
+            m.wait(b)                   # the slot's previous all-gather must finish before it is rewritten
+            dev_api.tt_layers_dev(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b))
             if gather:
-                works.append(dist.all_gather_into_tensor(full[b], shard[b], async_op=True))
+                m.gather(b, async_op=True)      # RCCL, overlaps the next step's kernel
+
+        def drain():
+            for b in range(slots):
+                m.wait(b)
     else:
         R = ref_inputs(wl)
         G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
@@ -144,11 +147,12 @@ def main():
             o = plan.run(geoms, xa, za, alpha, zf)
             mout = dev_api.match_dev(o["land_x"].view(G * T, N), o["tof"].view(G * T, N), x_rx, 1e-6, 1e-5, out=mout)
 
+        def drain():
+            pass
+
     for s in range(args.warmup):
         step(s)
-    for w in works:
-        w.wait()
-    works.clear()
+    drain()
     torch.cuda.synchronize()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,8 +162,7 @@ def main():
     for s in range(args.steps):
         step(s)
     ev1.record()
-    for w in works:
-        w.wait()
+    drain()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0

@@ -12,13 +12,24 @@
 // q stays finite even at grazing incidence (unlike p -> 1/cm).  Convergence is tested per wave
 // with a ballot so a wave leaves the loop as soon as all 64 lanes are done.
 //
+// Cost model (measured, scripts/ubench_fp64.hip): an fp64 fma/mul/add wave-op costs ~2 ns of SIMD
+// time, v_rsq_f64 / v_rcp_f64 ~6.8 ns (seed accuracy 5e-8), IEEE sqrt ~36 ns, IEEE divide ~25 ns.
+// So the iteration uses the raw rsq/rcp seeds (Newton does not need an exact Jacobian, and the
+// 5e-8 perturbation of the fixed point is removed below), and no IEEE sqrt/divide anywhere.
+//   * a lane stops when the step it would take is |dq| <= 1e-4 q; it does NOT take that step, so the
+//     seeds of its last evaluation belong to its q and are refined (one cubic step, ~1 ulp) instead
+//     of being recomputed;
+//   * T at the exact root follows from the Fermat expansion in the residual dXr = X - X(q):
+//     T = T(q) + p dXr + (1/2)(dp/dX) dXr^2,  p = dT/dX = sin(theta)/c  — error O(dXr^3) < 1e-17 s.
+//
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced,
 // the element coordinates and all layer constants are wave-uniform (SGPRs).
 #include "rtus_device.h"
 
 struct LayerArgs {
-    double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used)
+    double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used, +inf beyond)
     double c[RTUS_MAX_LAYERS + 1];     // speeds
+    double inv_c[RTUS_MAX_LAYERS + 1]; // 1/c (host-computed, correctly rounded)
     int n_if;
     const double* __restrict__ xe;
     const double* __restrict__ ze;
@@ -29,75 +40,119 @@ struct LayerArgs {
     int n_e, n_f;
 };
 
-// 1/sqrt(a) to ~1 ulp: hardware v_rsq_f64 seed + two Newton steps.
-__device__ __forceinline__ double rsqrt_nr(double a)
+// Refine a v_rsq seed y ~ a^(-1/2) (rel. error e0 ~ 5e-8) with one cubically convergent step:
+// e = 1 - a y^2,  y <- y (1 + e/2 + 3 e^2/8)   -> error ~ e0^3, i.e. rounding-limited.
+__device__ __forceinline__ double rsqrt_refine(double a, double y)
 {
-    double y = __builtin_amdgcn_rsq(a);
-    double h = 0.5 * a;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
+    const double e = fma(-a * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
 }
+
+// Seed for a^(-1/2), a >= 1: the fp32 pipe (cvt + v_rsq_f32 + cvt, ~3.6 ns) is cheaper than
+// v_rsq_f64 (~6.8 ns) at about the same accuracy (1e-7); a is clamped into float range.
+__device__ __forceinline__ double rsqrt_seed(double a)
+{
+    return (double)__builtin_amdgcn_rsqf((float)fmin(a, 1e37));
+}
+
+#define RTUS_EB 4   // elements per workgroup (same 256 focal points): layer set-up is reused when ze repeats
 
 template <int NL>   // NL = number of layers the medium has (n_if + 1)
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
 {
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
-    const int e = blockIdx.y;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
-    const double xe = a.xe[e], ze = a.ze[e];
     const double xf = a.xf[f], zf = a.zf[f];
-    const double X = fabs(xf - xe);
+    const int e0 = blockIdx.y * RTUS_EB;
+    const int e1 = min(e0 + RTUS_EB, a.n_e);
 
-    // thickness of each layer along the path (0 for layers below the focal point)
-    double h[NL], cm = 0.0;
+    double h[NL], hr[NL], kk[NL], hc[NL];
+    double inv_cm = 0.0, rs0 = 0.0, rhm = 0.0, asym = 0.0, ze_prev = NAN;
+    bool valid = false;
+    for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
+        const double xe = a.xe[e], ze = a.ze[e];
+        if (!(ze == ze_prev)) {                             // wave-uniform: redo the layer set-up only when ze changes
+            ze_prev = ze;
+            valid = zf > ze;
+            // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
+            double cm = 0.0;
+            inv_cm = 0.0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const double top = (i == 0) ? ze : fmax(a.z_if[i - 1], ze);
-        const double bot = (i < NL - 1) ? fmin(a.z_if[i], zf) : zf;
-        h[i] = fmax(bot - top, 0.0);
-        cm = (h[i] > 0.0) ? fmax(cm, a.c[i]) : cm;
-    }
-    double hr[NL], kk[NL], hc[NL], s0 = 0.0, asym = 0.0, hm = 0.0;
+            for (int i = 0; i < NL; ++i) {
+                const double top = (i == 0) ? ze : fmax(a.z_if[i - 1], ze);
+                const double bot = (i < NL - 1) ? fmin(a.z_if[i], zf) : zf;
+                h[i] = fmax(bot - top, 0.0);
+                const bool faster = h[i] > 0.0 && a.c[i] > cm;
+                cm = faster ? a.c[i] : cm;
+                inv_cm = faster ? a.inv_c[i] : inv_cm;
+            }
+            double s0 = 0.0, hm = 0.0;
+            asym = 0.0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const double r = a.c[i] / cm;
-        hr[i] = h[i] * r;
-        kk[i] = fmax(1.0 - r * r, 0.0);
-        hc[i] = h[i] / a.c[i];
-        s0 += hr[i];
-        // fastest layer(s): linear term h q; slower layers saturate at h r / sqrt(k)
-        if (kk[i] == 0.0) hm += h[i]; else asym += hr[i] * rsqrt_nr(kk[i]);
-    }
-    // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym
-    double q = fmax(X / s0, (X - asym) / hm);
-    int it = 0;
-    bool done = !(zf > ze);
-    while (true) {
-        double Xq = 0.0, dX = 0.0;
+            for (int i = 0; i < NL; ++i) {
+                const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
+                const double r = fastest ? 1.0 : a.c[i] * inv_cm;
+                hr[i] = h[i] * r;
+                hc[i] = h[i] * a.inv_c[i];
+                kk[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
+                s0 += hr[i];
+                // fastest layer(s): linear term h q; slower layers saturate at h r / sqrt(k) (guess only: raw seed)
+                hm += fastest ? h[i] : 0.0;
+                asym += fastest ? 0.0 : hr[i] * __builtin_amdgcn_rsq(kk[i]);
+            }
+            rs0 = __builtin_amdgcn_rcp(s0);
+            rhm = __builtin_amdgcn_rcp(hm);
+        }
+        const double X = fabs(xf - xe);
+        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym  (seed reciprocals: a guess)
+        double q = valid ? fmax(X * rs0, (X - asym) * rhm) : 0.0;
+        double y[NL], S1, S3;
+        int it = 0;
+        bool done = !valid;
+        while (true) {
+            const double q2 = q * q;
+            S1 = 0.0; S3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                y[i] = rsqrt_seed(fma(kk[i], q2, 1.0));
+                const double hw = hr[i] * y[i];
+                S1 += hw;
+                S3 = fma(hw, y[i] * y[i], S3);
+            }
+            const double dq = fma(-S1, q, X) * __builtin_amdgcn_rcp(S3);
+            // a lane is done when the step it WOULD take is small; it keeps q, so y[] stays the y of its q
+            done = done || !(fabs(dq) > 1e-4 * q) || it >= 60;
+            if (__all(done)) break;
+            if (!done) { q += dq; ++it; }
+        }
+        // Accurate T at q (not the exact root: |X - X(q)| <~ 1e-4 X) + the Fermat expansion in the
+        // residual dXr = X - X(q):  T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
+        // p = sin(theta)/cm = q u / cm,  dp/dX = u^3 / (cm X'(q)),  u = 1/sqrt(1+q^2).
+        const double q2 = q * q;
+        const double a1 = 1.0 + q2;
+        const double u = rsqrt_refine(a1, rsqrt_seed(a1));
+        double A1 = 0.0, A3 = 0.0, ST = 0.0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const double w = rsqrt_nr(fma(kk[i], q * q, 1.0));
+            const double w = rsqrt_refine(fma(kk[i], q2, 1.0), y[i]);
             const double hw = hr[i] * w;
-            Xq = fma(hw, q, Xq);
-            dX = fma(hw, w * w, dX);
+            A1 += hw;
+            A3 = fma(hw, w * w, A3);
+            ST = fma(hc[i], w, ST);
         }
-        const double dq = (X - Xq) / dX;
-        if (!done) { q += dq; ++it; }
-        done = done || !(fabs(dq) > 1e-11 * q) || it >= 60;
-        if (__all(done)) break;
+        const double dXr = fma(-A1, q, X);
+        const double p = q * u * inv_cm;
+        const double rA3 = __builtin_amdgcn_rcp(A3);       // only scales the 2nd-order term
+        const double half_dpdx = 0.5 * (u * u) * (u * inv_cm) * rA3;
+        double T = fma(a1 * u, ST, dXr * fma(half_dpdx, dXr, p));
+        if (!valid) T = NAN;
+        if (live) {
+            const size_t o = (size_t)e * a.n_f + f;
+            a.tt[o] = T;
+            if (a.iters) a.iters[o] = (uint8_t)it;
+        }
     }
-    // T at the converged q with correctly-rounded sqrt / divide
-    const double q2 = q * q, s1 = 1.0 + q2;
-    double T = 0.0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) T += hc[i] * sqrt(s1 / fma(kk[i], q2, 1.0));
-    if (!(zf > ze)) T = NAN;
-    if (!live) return;
-    const size_t o = (size_t)e * a.n_f + f;
-    a.tt[o] = T;
-    if (a.iters) a.iters[o] = (uint8_t)it;
 }
 
 hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
@@ -106,10 +161,10 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
 {
     LayerArgs a;
     for (int i = 0; i < RTUS_MAX_LAYERS; ++i) a.z_if[i] = i < n_if ? z_if[i] : INFINITY;
-    for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) a.c[i] = i <= n_if ? c[i] : 1.0;
+    for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) { a.c[i] = i <= n_if ? c[i] : 1.0; a.inv_c[i] = 1.0 / a.c[i]; }
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
     a.n_e = n_e; a.n_f = n_f;
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, n_e), block(RTUS_BLOCK);
+    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + RTUS_EB - 1) / RTUS_EB), block(RTUS_BLOCK);
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: hipLaunchKernelGGL(rtus_tt_layers_kernel<NL>, grid, block, 0, s, a); break;
         RTUS_CASE(1) RTUS_CASE(2) RTUS_CASE(3) RTUS_CASE(4) RTUS_CASE(5) RTUS_CASE(6) RTUS_CASE(7) RTUS_CASE(8)

@@ -1,0 +1,78 @@
+"""Multi-GPU sharding of the (tx element x target) travel-time matrix — one process per GPU.
+
+Every (element, target) solve is independent, so the matrix shards by contiguous tx-row blocks with
+no collective on the compute path.  The single exchange is the reassembly of the row blocks on every
+rank: an in-place ``all_gather_into_tensor`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the
+CPU tests).  Rows are padded to a multiple of the world size so all shards have equal size
+(SURVEY 8(e)); the pad rows are trimmed from the returned matrix.
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_shard(n_rows: int, world: int, rank: int):
+    """(lo, hi, rows_per_rank): rank owns rows [lo, hi) of the padded world*rows_per_rank layout."""
+    if n_rows <= 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad shard request")
+    per = -(-n_rows // world)
+    lo = min(rank * per, n_rows)
+    hi = min(lo + per, n_rows)
+    return lo, hi, per
+
+
+class RowShardedMatrix:
+    """Double-buffered full matrix [world*per, n_cols]; each rank's kernel writes directly into its
+    own row block (``local(slot)``), ``gather(slot)`` reassembles in place."""
+
+    def __init__(self, n_rows, n_cols, *, dtype=torch.float64, device="cuda", slots=2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.lo, self.hi, self.per = row_shard(self.n_rows, self.world, self.rank)
+        self.full = [torch.zeros((self.world * self.per, self.n_cols), dtype=dtype, device=device)
+                     for _ in range(slots)]
+        self._work = [None] * slots
+
+    def local(self, slot=0):
+        """The padded [per, n_cols] block this rank computes (rows beyond hi-lo are padding)."""
+        return self.full[slot][self.rank * self.per:(self.rank + 1) * self.per]
+
+    def wait(self, slot=0):
+        w = self._work[slot]
+        if w is not None:
+            w.wait()
+            self._work[slot] = None
+
+    def gather(self, slot=0, async_op=False):
+        """In-place all-gather of the row blocks.  With async_op the collective overlaps later work
+        on the current stream; call ``wait(slot)`` before reading or rewriting the slot."""
+        if self.world == 1:
+            return None
+        self.wait(slot)
+        w = dist.all_gather_into_tensor(self.full[slot], self.local(slot), group=self.group, async_op=async_op)
+        self._work[slot] = w if async_op else None
+        return w
+
+    def matrix(self, slot=0):
+        """The reassembled [n_rows, n_cols] matrix (pad rows trimmed)."""
+        self.wait(slot)
+        return self.full[slot][:self.n_rows]
+
+
+def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=None):
+    """Element x focal travel-time matrix computed by row shards on all ranks, gathered everywhere.
+
+    xe, ze, xf, zf: torch tensors on this rank's device holding the FULL element / focal lists.
+    ``solver(z_if, c, xe_shard, ze_shard, xf, zf, out)`` defaults to the HIP kernel; the CPU (gloo)
+    tests inject the oracle here — the product default never touches it.
+    """
+    if solver is None:
+        from .device import tt_layers_dev as solver
+    m = RowShardedMatrix(xe.numel(), xf.numel(), dtype=xe.dtype, device=xe.device, slots=1, group=group)
+    n_own = m.hi - m.lo
+    if n_own > 0:
+        solver(z_if, c, xe[m.lo:m.hi].contiguous(), ze[m.lo:m.hi].contiguous(), xf, zf,
+               out=m.local(0)[:n_own])
+    m.gather(0)
+    return m.matrix(0)
