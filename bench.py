@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2_planar",
                     choices=["cfg2_planar", "cfg3_planar", "ref_sweep", "ref_scale"])
-    ap.add_argument("--gather", default="on", choices=["on", "off"], help="RCCL all-gather when --gpus > 1")
+    ap.add_argument("--gather", default="end", choices=["end", "step", "off"],
+                    help="--gpus > 1: RCCL all-gather of the row shards once after the K steps (end), "
+                         "after every step overlapped with the next kernel (step), or never (off)")
+    ap.add_argument("--graph", default="on", choices=["on", "off"],
+                    help="replay the K timed steps as one captured hipGraph (N=1 or --gather end/off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the reference-path side measurements")
     return ap.parse_args()
@@ -107,7 +111,8 @@ def main():
 
     t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
     wl = args.workload
-    gather = world > 1 and args.gather == "on"
+    gather = world > 1 and args.gather == "step"
+    gather_end = world > 1 and args.gather == "end"
 
     if wl in ("cfg2_planar", "cfg3_planar"):
         W = planar_inputs(wl, rank, world)
@@ -117,20 +122,26 @@ def main():
         dist_api = import_module("ray-tracing-ultrasound_amd.dist")
         slots = 2 if gather else 1
         m = dist_api.RowShardedMatrix(world * n_e, n_f, device=dev, slots=slots)
+        plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)) for b in range(slots)]
         units_per_step = n_e * n_f
         alg_bytes = units_per_step * 8 + (2 * n_e + 2 * n_f) * 8
-        kernel = f"rtus_tt_layers_kernel<{len(W['c'])}>"
+        kernel = f"rtus_tt_layers_kernel<{len(W['c'])}, false>"
 
         def step(s):
             b = s % slots
-            m.wait(b)                   # the slot's previous all-gather must finish before it is rewritten
-            dev_api.tt_layers_dev(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b))
+            if gather:
+                m.wait(b)               # the slot's previous all-gather must finish before it is rewritten
+            plans[b].run()
             if gather:
                 m.gather(b, async_op=True)      # RCCL, overlaps the next step's kernel
 
         def drain():
             for b in range(slots):
                 m.wait(b)
+
+        def finish():                   # reassemble the last step's matrix on every rank (RCCL all-gather over xGMI)
+            if gather_end:
+                m.gather(0)
     else:
         R = ref_inputs(wl)
         G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
@@ -150,18 +161,48 @@ def main():
         def drain():
             pass
 
+        def finish():
+            pass
+
     for s in range(args.warmup):
         step(s)
+    finish()
     drain()
     torch.cuda.synchronize()
+
+    # The K timed steps are K back-to-back launches on one stream.  Python + hipLaunchKernel cost
+    # ~10 us per call, comparable to the kernel itself on cfg2, so the K launches are captured once
+    # into a hipGraph and replayed (same kernels, same order, no per-launch host work).
+    graph = None
+    if args.graph == "on" and not gather:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for s in range(args.steps):
+                        step(s)
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay()                      # one untimed replay (graph upload)
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as exc:            # capture unsupported -> eager launches
+            print(f"[bench] hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()                      # same (current) stream the library launches on
-    for s in range(args.steps):
-        step(s)
+    if graph is not None:
+        graph.replay()
+    else:
+        for s in range(args.steps):
+            step(s)
     ev1.record()
+    finish()
     drain()
     torch.cuda.synchronize()
     barrier()
@@ -187,7 +228,9 @@ def main():
             "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
             "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
             "solves_per_step_per_gpu": units_per_step,
-            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather overlapped" if gather else ""),
+            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather else
+                                                       ", RCCL all-gather of the final matrix" if gather_end else ""),
+            "launch": "hipGraph replay of K launches" if graph is not None else "eager launches",
         },
     }
     ach = alg_bytes / (kern_ms * 1e-3) / 1e9

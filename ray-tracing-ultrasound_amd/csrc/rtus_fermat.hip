@@ -25,6 +25,7 @@
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced,
 // the element coordinates and all layer constants are wave-uniform (SGPRs).
 #include "rtus_device.h"
+#include <stdlib.h>
 
 struct LayerArgs {
     double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used, +inf beyond)
@@ -38,6 +39,7 @@ struct LayerArgs {
     double* __restrict__ tt;
     uint8_t* __restrict__ iters;
     int n_e, n_f;
+    int eb;                            // elements per workgroup
 };
 
 // Refine a v_rsq seed y ~ a^(-1/2) (rel. error e0 ~ 5e-8) with one cubically convergent step:
@@ -49,31 +51,48 @@ __device__ __forceinline__ double rsqrt_refine(double a, double y)
 }
 
 // Seed for a^(-1/2), a >= 1: the fp32 pipe (cvt + v_rsq_f32 + cvt, ~3.6 ns) is cheaper than
-// v_rsq_f64 (~6.8 ns) at about the same accuracy (1e-7); a is clamped into float range.
+// v_rsq_f64 (~6.8 ns) at about the same accuracy (1e-7).  (a > 3e38 would need q > 1e19: not a ray.)
 __device__ __forceinline__ double rsqrt_seed(double a)
 {
-    return (double)__builtin_amdgcn_rsqf((float)fmin(a, 1e37));
+    return (double)__builtin_amdgcn_rsqf((float)a);
+}
+// Seed for 1/a through the fp32 pipe (1e-7); a must be within float range (sums of h r w^3: it is).
+__device__ __forceinline__ double rcp_seed(double a)
+{
+    return (double)__builtin_amdgcn_rcpf((float)a);
 }
 
-#define RTUS_EB 4   // elements per workgroup (same 256 focal points): layer set-up is reused when ze repeats
-
-template <int NL>   // NL = number of layers the medium has (n_if + 1)
+// A workgroup = 256 focal points x `eb` consecutive elements (loop).  Besides re-using the layer
+// set-up while ze repeats, the loop gives each lane a CONTINUATION PREDICTOR: the signed solution
+// qs = sign(xf - xe) q is a smooth function of the element position, so the two previous
+// solutions extrapolate the next one to ~1e-3..1e-4 and Newton needs ~2 evaluations instead of ~4.5.
+// The predictor is only a guess: every iterate is clamped to the rigorous lower bound of the root,
+// from which Newton is monotone, so convergence never depends on the elements being evenly spaced.
+template <int NL, bool ITERS>   // NL = number of layers the medium has (n_if + 1)
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
 {
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const double xf = a.xf[f], zf = a.zf[f];
-    const int e0 = blockIdx.y * RTUS_EB;
-    const int e1 = min(e0 + RTUS_EB, a.n_e);
+    const int e0 = blockIdx.y * a.eb;
+    const int e1 = min(e0 + a.eb, a.n_e);
+    // the workgroup's element coordinates: ONE vector load per wave (lane l holds element e0+l, eb <= 64),
+    // then v_readlane per loop trip — no memory latency inside the element loop.
+    const int lane = threadIdx.x & 63;
+    const int el = min(e0 + lane, a.n_e - 1);
+    const double xe_v = a.xe[el], ze_v = a.ze[el];
 
     double h[NL], hr[NL], kk[NL], hc[NL];
     double inv_cm = 0.0, rs0 = 0.0, rhm = 0.0, asym = 0.0, ze_prev = NAN;
+    double qs1 = 0.0, qs2 = 0.0, xe1 = 0.0, xe2 = 0.0;    // signed solutions / positions of the two previous elements
+    int hist = 0;
     bool valid = false;
     for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
-        const double xe = a.xe[e], ze = a.ze[e];
+        const double xe = __shfl(xe_v, e - e0), ze = __shfl(ze_v, e - e0);
         if (!(ze == ze_prev)) {                             // wave-uniform: redo the layer set-up only when ze changes
             ze_prev = ze;
+            hist = 0;
             valid = zf > ze;
             // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
             double cm = 0.0;
@@ -101,18 +120,27 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 hm += fastest ? h[i] : 0.0;
                 asym += fastest ? 0.0 : hr[i] * __builtin_amdgcn_rsq(kk[i]);
             }
-            rs0 = __builtin_amdgcn_rcp(s0);
-            rhm = __builtin_amdgcn_rcp(hm);
+            // lower-bound reciprocals rounded DOWN a little so that lb stays a lower bound
+            rs0 = __builtin_amdgcn_rcp(s0) * (1.0 - 1e-6);
+            rhm = __builtin_amdgcn_rcp(hm) * (1.0 - 1e-6);
         }
-        const double X = fabs(xf - xe);
-        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym  (seed reciprocals: a guess)
-        double q = valid ? fmax(X * rs0, (X - asym) * rhm) : 0.0;
-        double y[NL], S1, S3;
+        const double dxs = xf - xe;
+        const double X = fabs(dxs);
+        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym
+        const double lb = valid ? fmax(fmax(X * rs0, (X - asym) * rhm), 0.0) : 0.0;
+        double q = lb;
+        if (hist >= 2 && xe1 != xe2) {                      // wave-uniform
+            const double t = (xe - xe1) * rcp_seed(xe1 - xe2);
+            q = fmax(fabs(fma(qs1 - qs2, t, qs1)), lb);     // linear extrapolation of the signed solution
+        } else if (hist >= 1) {
+            q = fmax(fabs(qs1) * X * rcp_seed(fmax(fabs(xf - xe1), 1e-30)), lb);   // proportional
+        }
+        q = valid ? q : 0.0;
+        double y[NL];
         int it = 0;
-        bool done = !valid;
-        while (true) {
+        for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
             const double q2 = q * q;
-            S1 = 0.0; S3 = 0.0;
+            double S1 = 0.0, S3 = 0.0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 y[i] = rsqrt_seed(fma(kk[i], q2, 1.0));
@@ -120,11 +148,13 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 S1 += hw;
                 S3 = fma(hw, y[i] * y[i], S3);
             }
-            const double dq = fma(-S1, q, X) * __builtin_amdgcn_rcp(S3);
-            // a lane is done when the step it WOULD take is small; it keeps q, so y[] stays the y of its q
-            done = done || !(fabs(dq) > 1e-4 * q) || it >= 60;
-            if (__all(done)) break;
-            if (!done) { q += dq; ++it; }
+            const double dq = fma(-S1, q, X) * rcp_seed(S3);
+            // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
+            // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
+            const bool small = !(fabs(dq) > 1e-4 * q) || !valid;
+            if (__all(small)) break;
+            q = small ? q : fmax(q + dq, lb);
+            if (ITERS) it += small ? 0 : 1;
         }
         // Accurate T at q (not the exact root: |X - X(q)| <~ 1e-4 X) + the Fermat expansion in the
         // residual dXr = X - X(q):  T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
@@ -142,16 +172,20 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             ST = fma(hc[i], w, ST);
         }
         const double dXr = fma(-A1, q, X);
-        const double p = q * u * inv_cm;
-        const double rA3 = __builtin_amdgcn_rcp(A3);       // only scales the 2nd-order term
-        const double half_dpdx = 0.5 * (u * u) * (u * inv_cm) * rA3;
-        double T = fma(a1 * u, ST, dXr * fma(half_dpdx, dXr, p));
+        const double uc = u * inv_cm;
+        const double rA3 = rcp_seed(A3);                    // only scales the 2nd-order term / the predictor
+        double T = fma(a1 * u, ST, dXr * fma(0.5 * (u * u) * (uc * rA3), dXr, q * uc));
         if (!valid) T = NAN;
         if (live) {
             const size_t o = (size_t)e * a.n_f + f;
             a.tt[o] = T;
-            if (a.iters) a.iters[o] = (uint8_t)it;
+            if (ITERS) a.iters[o] = (uint8_t)it;
         }
+        // history for the predictor: the root itself, q + dXr / X'(q), signed by the side of the element
+        const double qroot = fma(dXr, rA3, q);
+        qs2 = qs1; xe2 = xe1;
+        qs1 = dxs < 0.0 ? -qroot : qroot; xe1 = xe;
+        ++hist;
     }
 }
 
@@ -164,9 +198,16 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
     for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) { a.c[i] = i <= n_if ? c[i] : 1.0; a.inv_c[i] = 1.0 / a.c[i]; }
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
     a.n_e = n_e; a.n_f = n_f;
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + RTUS_EB - 1) / RTUS_EB), block(RTUS_BLOCK);
+    // elements per workgroup: as many as possible (predictor + set-up reuse) while keeping >= ~4 waves per SIMD
+    const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
+    int eb = (int)(wave_solves / (1024LL * 4));
+    eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
+    if (const char* ev = getenv("RTUS_EB")) { int v = atoi(ev); if (v >= 1 && v <= 64) eb = v; }   // tuning override
+    a.eb = eb;
+    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb), block(RTUS_BLOCK);
     switch (n_if + 1) {
-#define RTUS_CASE(NL) case NL: hipLaunchKernelGGL(rtus_tt_layers_kernel<NL>, grid, block, 0, s, a); break;
+#define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true>), grid, block, 0, s, a); \
+                               else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false>), grid, block, 0, s, a); break;
         RTUS_CASE(1) RTUS_CASE(2) RTUS_CASE(3) RTUS_CASE(4) RTUS_CASE(5) RTUS_CASE(6) RTUS_CASE(7) RTUS_CASE(8)
         RTUS_CASE(9)
 #undef RTUS_CASE

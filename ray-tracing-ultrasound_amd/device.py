@@ -85,3 +85,34 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
                                        _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
     _lib.check(st, "rtus_tt_layers_dev")
     return out
+
+
+class LayersPlan:
+    """Pre-bound ``rtus_tt_layers_dev`` call for repeated solves of one shape: ``run()`` is a single
+    ctypes call (no argument checking, no allocation, no sync) — capturable in a hipGraph."""
+
+    def __init__(self, z_if, c, xe, ze, xf, zf, out=None, iters=None):
+        import numpy as np
+        self.z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
+        self.c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+        if self.c.size != self.z_if.size + 1:
+            raise ValueError("need len(c) == len(z_if) + 1")
+        for t, n in ((xe, "xe"), (ze, "ze"), (xf, "xf"), (zf, "zf")):
+            _chk(t, n)
+        self.n_e, self.n_f = xe.numel(), xf.numel()
+        if ze.numel() != self.n_e or zf.numel() != self.n_f:
+            raise ValueError("xe/ze and xf/zf must pair up")
+        self.out = out if out is not None else torch.empty((self.n_e, self.n_f), dtype=torch.float64, device=xe.device)
+        _chk(self.out, "out")
+        if self.out.numel() != self.n_e * self.n_f:
+            raise ValueError("out has the wrong size")
+        self._keep = (xe, ze, xf, zf, self.out, iters)
+        self._fn = _lib.lib().rtus_tt_layers_dev
+        self._args = [self.z_if.ctypes.data if self.z_if.size else None, self.c.ctypes.data, self.z_if.size,
+                      _p(xe), _p(ze), self.n_e, _p(xf), _p(zf), self.n_f, _p(self.out), _p(iters)]
+
+    def run(self, stream=None):
+        st = self._fn(*self._args, _stream() if stream is None else stream)
+        if st:
+            _lib.check(st, "rtus_tt_layers_dev")
+        return self.out

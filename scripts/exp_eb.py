@@ -1,0 +1,24 @@
+import os, sys, numpy as np
+sys.path.insert(0,'.')
+import torch, rtus
+from importlib import import_module
+dev_api=import_module("ray-tracing-ultrasound_amd.device")
+dev=torch.device('cuda')
+t64=lambda a: torch.as_tensor(np.ascontiguousarray(a,dtype=np.float64),device=dev)
+n_e,g=128,128
+xe=(np.arange(n_e)-(n_e-1)/2)*0.6e-3
+xs,zs=np.meshgrid(np.linspace(-0.02,0.02,g),np.linspace(0.025,0.065,g))
+plan=dev_api.LayersPlan([0.02],[2330.,1483.],t64(xe),t64(np.zeros(n_e)),t64(xs.ravel()),t64(zs.ravel()))
+for eb in (1,2,4,8,16,32,64):
+    os.environ['RTUS_EB']=str(eb)
+    for _ in range(5): plan.run()
+    torch.cuda.synchronize()
+    gph=torch.cuda.CUDAGraph()
+    s=torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(gph,stream=s):
+            for _ in range(100): plan.run()
+    gph.replay(); torch.cuda.synchronize()
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record(); gph.replay(); e1.record(); torch.cuda.synchronize()
+    print(f"eb={eb:3d}  {e0.elapsed_time(e1)/100*1e3:7.2f} us/launch")
