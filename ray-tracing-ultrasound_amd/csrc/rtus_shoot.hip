@@ -1,20 +1,26 @@
 // rtus_shoot.hip — forward 4-segment ray trace (reference shoot_rays, main_rt.py:337-405) for
 // gfx950: one ray per lane, 64-lane waves walking the lens polyline in lock-step.
 //
-// Layout in HBM
-//   curve   double2[n]      (x_p, z_p) of the alpha grid     — shared by every tx / geometry
-//   phi_s   double[n]       atan2(dz, dx) of the lens tangent at alpha[j]
-//   blk     double4[n/64]   (xmin, xmax, zmin, zmax) of each 64-point polyline block
+// Layout in HBM (workspace, built once per call by rtus_curve_kernel; shared by every tx / geometry)
+//   curve   double2[n]        (x_p, z_p) of the alpha grid
+//   phi_s   double[n]         atan2(dz, dx) of the lens tangent at alpha[j]
+//   node0   double4[n/8]      bounding box (xc, xh, zc, zh = centre / half-extent) of 8 polyline points
+//   node1   double4[n/64]     ... of 64 points
+//   node2   double4[n/512]    ... of 512 points
 //   out8    [n_geom][n_tx][8][n]   SoA per (geometry, tx): every store is a coalesced 512-B row
 //
 // Crossing search (reference find_line_curve_intersection, main_rt.py:78-99: FIRST index j with
 // sign(d_j) != sign(d_{j+1}), d_j = z_p[j] - (m x_p[j] + b)).  The reference scans all n points
-// per ray.  Here a wave scans in lock-step: the polyline index is wave-uniform, so polyline
-// points arrive by scalar loads (SGPRs, broadcast for free) and each lane only evaluates its
-// own line.  A 64-point block is skipped when EVERY lane's line is provably on one side of the
-// block's bounding box by more than a rounding margin — the skip cannot change which index is
-// found, it only avoids evaluating points whose sign is already certain.
+// per ray (90 % of its run time).  Here a wave scans in lock-step: the polyline index is
+// wave-uniform, so polyline points and boxes arrive by scalar loads (SGPRs, broadcast for free)
+// and each lane only evaluates its own line.  A box (512 -> 64 -> 8 points) is skipped when EVERY
+// lane's line is provably on one side of it by more than a rounding margin; otherwise the wave
+// descends, and only 8-point leaves are evaluated point by point.  Skipping cannot change which
+// index is found — it only avoids evaluating points whose sign is already certain — so the result
+// is the reference's "first sign change in index order", np.sign(0) = 0 semantics included.
 #include "rtus_device.h"
+
+#define RTUS_CURVE_TPB 512      // curve kernel: one workgroup = one 512-point node2
 
 struct ShootArgs {
     LensK k;
@@ -24,23 +30,35 @@ struct ShootArgs {
     const double* __restrict__ z_f;     // [n]
     const double2* __restrict__ curve;  // [n]
     const double* __restrict__ phi_s;   // [n]
-    const double4* __restrict__ blk;    // [nblk]
+    const double4* __restrict__ node0;  // [n0]
+    const double4* __restrict__ node1;  // [n1]
+    const double4* __restrict__ node2;  // [n2]
     double* __restrict__ out8;          // nullable
     double* __restrict__ tof4;          // nullable
     double* __restrict__ tof;           // nullable
     double* __restrict__ land_x;        // nullable
     uint8_t* __restrict__ status;       // nullable
-    int n, n_tx, n_geom, nblk;
+    int n, n_tx, n_geom, n0, n1, n2;
 };
 
-// ---- polyline + per-block bounding boxes -----------------------------------------------------
-// One wave per 64-point block: lanes compute (x_p, z_p, phi_s) then min/max-reduce across the wave.
-__global__ __launch_bounds__(RTUS_BLOCK) void rtus_curve_kernel(LensK k, const double* __restrict__ alpha,
-                                                                 int n, double2* __restrict__ curve,
-                                                                 double* __restrict__ phi_s,
-                                                                 double4* __restrict__ blk)
+__device__ __forceinline__ double4 make_box(double xmin, double xmax, double zmin, double zmax)
 {
-    const int j = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    // centre / half-extent, half-extents nudged up so the box still contains its points after rounding
+    const double xc = 0.5 * (xmin + xmax), zc = 0.5 * (zmin + zmax);
+    const double xh = fmax(xmax - xc, xc - xmin) * (1.0 + 1e-15), zh = fmax(zmax - zc, zc - zmin) * (1.0 + 1e-15);
+    return make_double4(xc, xh, zc, zh);
+}
+
+// ---- polyline + bounding-box hierarchy -------------------------------------------------------
+__global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, const double* __restrict__ alpha,
+                                                                     int n, double2* __restrict__ curve,
+                                                                     double* __restrict__ phi_s,
+                                                                     double4* __restrict__ node0,
+                                                                     double4* __restrict__ node1,
+                                                                     double4* __restrict__ node2)
+{
+    __shared__ double red[4][RTUS_CURVE_TPB / 64];
+    const int j = blockIdx.x * RTUS_CURVE_TPB + threadIdx.x;
     double x = 0, z = 0, dz, dx;
     const bool live = j < n;
     if (live) {
@@ -51,13 +69,51 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_curve_kernel(LensK k, const d
     double xmin = live ? x : INFINITY, xmax = live ? x : -INFINITY;
     double zmin = live ? z : INFINITY, zmax = live ? z : -INFINITY;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 1; o < 64; o <<= 1) {
         xmin = fmin(xmin, __shfl_xor(xmin, o));
         xmax = fmax(xmax, __shfl_xor(xmax, o));
         zmin = fmin(zmin, __shfl_xor(zmin, o));
         zmax = fmax(zmax, __shfl_xor(zmax, o));
+        if (o == 4 && (threadIdx.x & 7) == 0 && live) node0[j >> 3] = make_box(xmin, xmax, zmin, zmax);
     }
-    if ((threadIdx.x & 63) == 0 && live) blk[j >> 6] = make_double4(xmin, xmax, zmin, zmax);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        if (live) node1[j >> 6] = make_box(xmin, xmax, zmin, zmax);
+        red[0][wv] = xmin; red[1][wv] = xmax; red[2][wv] = zmin; red[3][wv] = zmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RTUS_CURVE_TPB / 64; ++w) {
+            xmin = fmin(xmin, red[0][w]); xmax = fmax(xmax, red[1][w]);
+            zmin = fmin(zmin, red[2][w]); zmax = fmax(zmax, red[3][w]);
+        }
+        node2[blockIdx.x] = make_box(xmin, xmax, zmin, zmax);
+    }
+}
+
+// Per-lane line + search state for the lock-step walk.
+struct LineState {
+    double m, b, am, marg;   // line z = m x + b; |m|; certification margin
+    bool found;              // first sign change located (or the line is non-finite: nothing to find)
+    int idx;                 // its index (segment idx .. idx+1), -1 if none
+    int pcls;                // class of the previous polyline point: -1 / 0 / +1, 2 = no point seen yet
+};
+
+// Is the whole box on one side of the line?  +1: every d_j > 0, -1: every d_j < 0, 0: cannot tell.
+__device__ __forceinline__ int certify(const LineState& L, const double4 bx)
+{
+    const double e = bx.z - fma(L.m, bx.x, L.b);         // d at the box centre
+    const double s = fma(L.am, bx.y, bx.w) + L.marg;     // how far d can move inside the box + margin
+    return e > s ? 1 : (e < -s ? -1 : 0);
+}
+
+// A certified box: all its points have class c.  A change against the previous point is a hit at j0-1.
+__device__ __forceinline__ void pass_box(LineState& L, int c, int j0)
+{
+    if (!L.found) {
+        if (L.pcls != 2 && L.pcls != c) { L.found = true; L.idx = j0 - 1; }
+        L.pcls = c;
+    }
 }
 
 // ---- the forward trace -----------------------------------------------------------------------
@@ -101,45 +157,71 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 
     // --- first sign change of d_j along the polyline (main_rt.py:78-99) -----------------------
     const bool fin = isfinite(m) && isfinite(b);   // non-finite line -> the reference ends in (None, None)
-    bool found = !fin;
-    int idx = -1;
-    bool p_lt = false, p_gt = false;
-    for (int B = 0; B < a.nblk; ++B) {
-        if (__all(found)) break;
-        const double4 bb = a.blk[B];               // wave-uniform -> scalar load
-        const double t0 = fma(m, bb.x, b), t1 = fma(m, bb.y, b);
-        const double tmax = fmax(t0, t1), tmin = fmin(t0, t1);
-        const double margin = 2e-8 + 1e-13 * (fabs(t0) + fabs(t1) + fabs(bb.z) + fabs(bb.w));
-        const bool cpos = (bb.z - tmax) > margin;  // every d_j in the block > 0
-        const bool cneg = (bb.w - tmin) < -margin; // every d_j in the block < 0
-        if (__any(!found && !(cpos || cneg))) {
-            const int j0 = B * RTUS_CURVE_BLK;
-            const int j1 = min(j0 + RTUS_CURVE_BLK, n);
-            for (int j = j0; j < j1; ++j) {
-                const double2 c = a.curve[j];      // wave-uniform -> scalar load
-                const double t = fma(m, c.x, b);
-                const bool lt = c.y < t, gt = c.y > t;
-                const bool chg = (lt != p_lt) | (gt != p_gt);
-                if (!found && j > 0 && chg) { found = true; idx = j - 1; }
-                p_lt = lt; p_gt = gt;
+    // polyline extent (for the rounding part of the margin): a handful of wave-uniform box reads
+    double xabs = 0.0, zabs = 0.0;
+    for (int s = 0; s < a.n2; ++s) {
+        const double4 bx = a.node2[s];
+        xabs = fmax(xabs, fabs(bx.x) + bx.y);
+        zabs = fmax(zabs, fabs(bx.z) + bx.w);
+    }
+    LineState L;
+    L.m = m; L.b = b; L.am = fabs(m);
+    // 2e-8 >= the reference's isclose(d, 0) atol, so a skipped box can hold no "point on the line"
+    // (main_rt.py:86); the relative part is ~450x the worst fp64 rounding of d_j.
+    L.marg = 2e-8 + 1e-13 * (fma(L.am, xabs, fabs(b)) + zabs);
+    L.found = !fin; L.idx = -1; L.pcls = 2;
+
+    for (int S = 0; S < a.n2; ++S) {
+        if (__all(L.found)) break;
+        const int c2 = certify(L, a.node2[S]);                         // wave-uniform index -> scalar load
+        if (!__any(!L.found && c2 == 0)) { pass_box(L, c2, S * 512); continue; }
+        const int B1 = min(S * 8 + 8, a.n1);
+        for (int B = S * 8; B < B1; ++B) {
+            const int c1 = certify(L, a.node1[B]);
+            if (!__any(!L.found && c1 == 0)) { pass_box(L, c1, B * 64); continue; }
+            const int U1 = min(B * 8 + 8, a.n0);
+            for (int U = B * 8; U < U1; ++U) {
+                const int c0 = certify(L, a.node0[U]);
+                if (!__any(!L.found && c0 == 0)) { pass_box(L, c0, U * 8); continue; }
+                const int j1 = min(U * 8 + 8, n);
+                for (int j = U * 8; j < j1; ++j) {                      // leaf: point by point
+                    const double2 c = a.curve[j];
+                    const double t = fma(m, c.x, b);
+                    const int cls = (c.y > t) - (c.y < t);             // np.sign(d_j)
+                    if (!L.found && L.pcls != 2 && cls != L.pcls) { L.found = true; L.idx = j - 1; }
+                    L.pcls = cls;
+                }
             }
-        } else if (!found) {
-            if (B > 0 && ((cneg != p_lt) | (cpos != p_gt))) { found = true; idx = B * RTUS_CURVE_BLK - 1; }
-            p_lt = cneg; p_gt = cpos;
         }
     }
+    const int idx = L.idx;
 
     double xi = NAN, zi = NAN;
     // No sign change anywhere: first polyline point within isclose(d, 0) of the line, else None
-    // (main_rt.py:84-96).  Rare; brute-force pass only for waves that need it.
-    if (__any(fin && idx < 0)) {
-        int on = -1;
-        for (int j = 0; j < n; ++j) {
-            const double2 c = a.curve[j];
-            const double dj = c.y - (m * c.x + b);
-            if (on < 0 && fabs(dj) <= 1e-8) on = j;
+    // (main_rt.py:84-96).  Such a point can only sit in a box the line could not be certified
+    // against, so the same walk finds it; lines that miss the lens by a clear margin cost only
+    // the top-level box tests.
+    const bool need_on = fin && idx < 0;
+    if (__any(need_on)) {
+        int on = 0x7fffffff;
+        for (int S = 0; S < a.n2; ++S) {
+            if (!__any(need_on && certify(L, a.node2[S]) == 0)) continue;
+            const int B1 = min(S * 8 + 8, a.n1);
+            for (int B = S * 8; B < B1; ++B) {
+                if (!__any(need_on && certify(L, a.node1[B]) == 0)) continue;
+                const int U1 = min(B * 8 + 8, a.n0);
+                for (int U = B * 8; U < U1; ++U) {
+                    if (!__any(need_on && certify(L, a.node0[U]) == 0)) continue;
+                    const int j1 = min(U * 8 + 8, n);
+                    for (int j = U * 8; j < j1; ++j) {
+                        const double2 c = a.curve[j];
+                        const double dj = c.y - (m * c.x + b);        // :78-79, NumPy rounding
+                        if (fabs(dj) <= 1e-8) on = min(on, j);         // :86 isclose(diffs, 0)
+                    }
+                }
+            }
         }
-        if (fin && idx < 0 && on >= 0) { const double2 c = a.curve[on]; xi = c.x; zi = c.y; }
+        if (need_on && on != 0x7fffffff) { const double2 c = a.curve[on]; xi = c.x; zi = c.y; }   // :88-90
     }
     if (idx >= 0) {                                                    // main_rt.py:106-168
         const double2 c1p = a.curve[idx], c2p = a.curve[idx + 1];
@@ -197,10 +279,12 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 }
 
 // ---- host-side launchers (called from rtus_capi.hip) -----------------------------------------
-size_t rtus_ws_curve_off(int) { return 0; }
-size_t rtus_ws_phis_off(int n) { return (size_t)n * sizeof(double2); }
-size_t rtus_ws_blk_off(int n) { return (((size_t)n * 24) + 31) & ~(size_t)31; }
-size_t rtus_ws_bytes(int n) { return rtus_ws_blk_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
+static size_t align32(size_t v) { return (v + 31) & ~(size_t)31; }
+static size_t ws_phis_off(int n) { return align32((size_t)n * sizeof(double2)); }
+static size_t ws_node0_off(int n) { return align32(ws_phis_off(n) + (size_t)n * sizeof(double)); }
+static size_t ws_node1_off(int n) { return ws_node0_off(n) + (size_t)((n + 7) / 8) * sizeof(double4); }
+static size_t ws_node2_off(int n) { return ws_node1_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
+size_t rtus_ws_bytes(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
 
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
@@ -211,14 +295,18 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     ShootArgs a;
     a.k = make_lens_k(lens);
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f;
-    a.curve = (const double2*)(w + rtus_ws_curve_off(n));
-    a.phi_s = (const double*)(w + rtus_ws_phis_off(n));
-    a.blk = (const double4*)(w + rtus_ws_blk_off(n));
+    a.curve = (const double2*)w;
+    a.phi_s = (const double*)(w + ws_phis_off(n));
+    a.node0 = (const double4*)(w + ws_node0_off(n));
+    a.node1 = (const double4*)(w + ws_node1_off(n));
+    a.node2 = (const double4*)(w + ws_node2_off(n));
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
-    a.n = n; a.n_tx = n_tx; a.n_geom = n_geom; a.nblk = (n + 63) / 64;
-    const int gx = (n + RTUS_BLOCK - 1) / RTUS_BLOCK;
-    hipLaunchKernelGGL(rtus_curve_kernel, dim3(gx), dim3(RTUS_BLOCK), 0, s, a.k, alpha, n,
-                       (double2*)a.curve, (double*)a.phi_s, (double4*)a.blk);
-    hipLaunchKernelGGL(rtus_shoot_kernel, dim3(gx, n_tx, n_geom), dim3(RTUS_BLOCK), 0, s, a);
+    a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
+    a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
+                       (double2*)a.curve, (double*)a.phi_s, (double4*)a.node0, (double4*)a.node1,
+                       (double4*)a.node2);
+    hipLaunchKernelGGL(rtus_shoot_kernel, dim3((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom),
+                       dim3(RTUS_BLOCK), 0, s, a);
     return hipGetLastError();
 }
