@@ -149,6 +149,39 @@ int rtus_tt_layers(const double *z_if, const double *c, int n_if,
                    const double *xf, const double *zf, int n_f,
                    double *tt, uint8_t *iters, int device);
 
+/* ------------------------------------------------------------------------------------------
+ * Element x focal-point Fermat travel times through the reference's CURVED lens surface
+ * (BASELINE config 4).  Interface = P(alpha) = h(alpha)(sin alpha, cos alpha) with h, dh/dalpha of
+ * main_rt.py:180-214 (x_z_from_alpha :217-223, dz_dx_from_alpha :226-234); element in the lens
+ * (c1), target in the water (c2).  The reference has no two-point solver (it only shoots rays from a
+ * launch-angle grid, main_rt.py:479-482), so as a SOLVER this is the build's own; it is pinned to the
+ * reference through Fermat <=> Snell: for a forward-traced ray, (A, F = pipe point) must give back
+ * that ray's alpha and tof_1 + tof_2 (main_compare.py:514-515).
+ *
+ *   alpha_lo/hi    search interval for the refraction point's polar angle (e.g. -/+ alpha_max, main_rt.py:457)
+ *   xe,ze [n_e]    elements;  xf,zf [n_f]  targets
+ *   tt [n_e][n_f]  travel times;  alpha_out [n_e][n_f] nullable: polar angle of the refraction point
+ * ---------------------------------------------------------------------------------------- */
+int rtus_tt_lens_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                     const double *d_xe, const double *d_ze, int n_e,
+                     const double *d_xf, const double *d_zf, int n_f,
+                     double *d_tt, double *d_alpha_out, void *stream);
+
+int rtus_tt_lens(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                 const double *xe, const double *ze, int n_e,
+                 const double *xf, const double *zf, int n_f,
+                 double *tt, double *alpha_out, int device);
+
+int rtus_tt_lens_f32_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                         const float *d_xe, const float *d_ze, int n_e,
+                         const float *d_xf, const float *d_zf, int n_f,
+                         float *d_tt, float *d_alpha_out, void *stream);
+
+int rtus_tt_lens_f32(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                     const float *xe, const float *ze, int n_e,
+                     const float *xf, const float *zf, int n_f,
+                     float *tt, float *alpha_out, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,8 @@ def lib():
         L.orc_tt_layers.restype = None
         L.orc_tt_layers_newton.argtypes = L.orc_tt_layers.argtypes
         L.orc_tt_layers_newton.restype = None
+        L.orc_tt_lens.argtypes = [C.POINTER(_Lens), C.c_double, C.c_double, _dp, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.orc_tt_lens.restype = None
         L.orc_lens_point.argtypes = [C.POINTER(_Lens), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lens_point.restype = None
         L.orc_num_threads.restype = C.c_int
@@ -118,6 +120,16 @@ def tt_layers_newton(z_if, c, xe, ze, xf, zf):
     tt = np.empty((xe.size, xf.size), dtype=np.float64)
     lib().orc_tt_layers_newton(z_if, c, z_if.size, xe, ze, xe.size, xf, zf, xf.size, tt)
     return tt
+
+
+def tt_lens(xe, ze, xf, zf, a_lo, a_hi, lens=REF_LENS):
+    """Two-point Fermat times through the lens surface by golden-section search (long double)."""
+    xe, ze, xf, zf = map(_f64, (xe, ze, xf, zf))
+    tt = np.empty((xe.size, xf.size), dtype=np.float64)
+    al = np.empty((xe.size, xf.size), dtype=np.float64)
+    L = _lens(**lens)
+    lib().orc_tt_lens(C.byref(L), a_lo, a_hi, xe, ze, xe.size, xf, zf, xf.size, tt, al)
+    return tt, al
 
 
 def num_threads():

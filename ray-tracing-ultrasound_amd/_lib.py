@@ -77,6 +77,12 @@ def lib():
     L.rtus_ray_hits.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, ip]
     L.rtus_tt_layers_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, vp]
     L.rtus_tt_layers.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, ip]
+    L.rtus_tt_lens_dev.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, vp]
+    L.rtus_tt_lens.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, ip]
+    L.rtus_tt_lens_f32_dev.argtypes = L.rtus_tt_lens_dev.argtypes
+    L.rtus_tt_lens_f32.argtypes = L.rtus_tt_lens.argtypes
+    for name in ("rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32"):
+        getattr(L, name).restype = ip
     for name in ("rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match", "rtus_ray_hits_dev",
                  "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_device_count"):
         getattr(L, name).restype = ip
@@ -91,4 +97,5 @@ def check(status, what):
 
 EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count",
            "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
-           "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers")
+           "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers",
+           "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32")

@@ -190,3 +190,50 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, device=0)
                                    xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), int(device))
     _lib.check(st, "rtus_tt_layers")
     return (tt, iters) if return_iters else tt
+
+
+def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, alpha_hi=None, dtype=np.float64,
+                     return_alpha=False, device=0):
+    """Element x focal-point Fermat travel times through the reference's curved lens surface
+    (h(alpha) of main_rt.py:180-189): elements in the lens (c1), targets in the water (c2) -> tt[n_e, n_f].
+
+    dtype float32 runs the fp32 kernel (BASELINE config 4).  ``return_alpha`` also returns the polar
+    angle of the refraction point.  As a two-point solver this is not in the reference; it is pinned to
+    it through Fermat <=> Snell (see include/rtus.h).
+    """
+    p = _resolve(params)
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError("dtype must be float64 or float32")
+    a_lo = -ALPHA_MAX if alpha_lo is None else float(alpha_lo)
+    a_hi = ALPHA_MAX if alpha_hi is None else float(alpha_hi)
+    arr = [np.atleast_1d(np.ascontiguousarray(v, dtype=dt)) for v in (xe, ze, xf, zf)]
+    xe, ze, xf, zf = arr
+    if xe.shape != ze.shape or xf.shape != zf.shape or xe.ndim != 1 or xf.ndim != 1:
+        raise ValueError("xe/ze and xf/zf must be 1-D and pair up")
+    tt = np.empty((xe.size, xf.size), dtype=dt)
+    al = np.empty((xe.size, xf.size), dtype=dt) if return_alpha else None
+    lens = p.lens()
+    fn = _lib.lib().rtus_tt_lens if dt == np.float64 else _lib.lib().rtus_tt_lens_f32
+    st = fn(C.byref(lens), a_lo, a_hi, _ptr(xe), _ptr(ze), xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(al),
+            int(device))
+    _lib.check(st, "rtus_tt_lens")
+    return (tt, al) if return_alpha else tt
+
+
+def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0):
+    """Full-matrix-capture tx/rx travel-time table for a planar specular reflector at depth z_reflector
+    under horizontal layers (BASELINE config 5).  The down-and-up path through the layers is unfolded
+    about the reflector plane into a one-way path through the mirrored stack, so the table is one
+    travel_time_layers call: tt[n_tx, n_rx].  Not in the reference (parity unpinned)."""
+    z_if = np.asarray(z_if, dtype=np.float64).reshape(-1)
+    c = np.asarray(c, dtype=np.float64).reshape(-1)
+    if c.size != z_if.size + 1:
+        raise ValueError("need len(c) == len(z_if) + 1")
+    above = z_if < z_reflector
+    zi, cc = z_if[above], c[:above.sum() + 1]
+    z_m = np.concatenate([zi, (2.0 * z_reflector - zi)[::-1]])          # mirrored interfaces
+    c_m = np.concatenate([cc, cc[::-1][1:]])                            # ... and speeds (reflector layer merged)
+    x_tx, x_rx = _f64(x_tx, "x_tx"), _f64(x_rx, "x_rx")
+    return travel_time_layers(z_m, c_m, x_tx, np.full(x_tx.size, float(z_array)), x_rx,
+                              np.full(x_rx.size, 2.0 * z_reflector - float(z_array)), device=device)

@@ -19,6 +19,13 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
                                  double* tt, uint8_t* iters, hipStream_t s);
 
+hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
+                                   int n_e, const double* xf, const double* zf, int n_f, double* tt,
+                                   double* alpha_out, hipStream_t s);
+hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi, const float* xe, const float* ze,
+                                   int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
+                                   hipStream_t s);
+
 static thread_local int g_last_hip = 0;
 static int hip_fail(hipError_t e) { g_last_hip = (int)e; return RTUS_ERR_HIP; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
@@ -42,6 +49,39 @@ static int select_device(int device)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return RTUS_ERR_NO_DEVICE;
     HIP_TRY(hipSetDevice(device));
+    return RTUS_OK;
+}
+
+// curved-lens helpers (C++ linkage: templates)
+static int check_lens(const rtus_lens* lens, double a_lo, double a_hi, const void* xe, const void* ze, int n_e,
+                      const void* xf, const void* zf, int n_f, const void* tt)
+{
+    if (!lens || !xe || !ze || !xf || !zf || !tt || n_e <= 0 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
+    if (!(a_hi > a_lo) || !isfinite(a_lo) || !isfinite(a_hi)) return RTUS_ERR_INVALID_ARG;
+    if (!(lens->c1 > 0) || !(lens->c2 > 0) || lens->c1 == lens->c2) return RTUS_ERR_INVALID_ARG;
+    return RTUS_OK;
+}
+
+template <typename R, typename F>
+static int lens_host(const rtus_lens* lens, double a_lo, double a_hi, const R* xe, const R* ze, int n_e, const R* xf,
+                     const R* zf, int n_f, R* tt, R* alpha_out, int device, F launch)
+{
+    int st = check_lens(lens, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt);
+    if (st) return st;
+    if ((st = select_device(device))) return st;
+    const size_t tot = (size_t)n_e * n_f;
+    DevBuf dxe, dze, dxf, dzf, dtt, dal;
+    HIP_TRY(dxe.upload(xe, sizeof(R) * n_e));
+    HIP_TRY(dze.upload(ze, sizeof(R) * n_e));
+    HIP_TRY(dxf.upload(xf, sizeof(R) * n_f));
+    HIP_TRY(dzf.upload(zf, sizeof(R) * n_f));
+    HIP_TRY(dtt.alloc(sizeof(R) * tot));
+    if (alpha_out) HIP_TRY(dal.alloc(sizeof(R) * tot));
+    HIP_TRY(launch(*lens, a_lo, a_hi, dxe.as<R>(), dze.as<R>(), n_e, dxf.as<R>(), dzf.as<R>(), n_f, dtt.as<R>(),
+                   dal.as<R>(), (hipStream_t)0));
+    HIP_TRY(hipStreamSynchronize(0));
+    HIP_TRY(hipMemcpy(tt, dtt.p, sizeof(R) * tot, hipMemcpyDeviceToHost));
+    if (alpha_out) HIP_TRY(hipMemcpy(alpha_out, dal.p, sizeof(R) * tot, hipMemcpyDeviceToHost));
     return RTUS_OK;
 }
 
@@ -270,6 +310,43 @@ int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* 
     HIP_TRY(hipMemcpy(tt, dtt.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
     if (iters) HIP_TRY(hipMemcpy(iters, dit.p, tot, hipMemcpyDeviceToHost));
     return RTUS_OK;
+}
+
+// ---------------------------------------------------------------------------- curved lens
+int rtus_tt_lens_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const double* d_xe, const double* d_ze,
+                     int n_e, const double* d_xf, const double* d_zf, int n_f, double* d_tt, double* d_alpha_out,
+                     void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
+    if (st) return st;
+    HIP_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+                                    (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tt_lens_f32_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* d_xe, const float* d_ze,
+                         int n_e, const float* d_xf, const float* d_zf, int n_f, float* d_tt, float* d_alpha_out,
+                         void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
+    if (st) return st;
+    HIP_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+                                    (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tt_lens(const rtus_lens* lens, double alpha_lo, double alpha_hi, const double* xe, const double* ze, int n_e,
+                 const double* xf, const double* zf, int n_f, double* tt, double* alpha_out, int device)
+{
+    return lens_host<double>(lens, alpha_lo, alpha_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, device,
+                             rtus_launch_tt_lens_f64);
+}
+
+int rtus_tt_lens_f32(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* xe, const float* ze,
+                     int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out, int device)
+{
+    return lens_host<float>(lens, alpha_lo, alpha_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, device,
+                            rtus_launch_tt_lens_f32);
 }
 
 }   // extern "C"

@@ -122,3 +122,31 @@ def test_line_curve_corner_cases():
     assert run(1.0, 0.0, [0.0, 1.0, 2.0], [1e-12, 1.0, 3.0]) == (0.5, 0.5)
     # vertical curve segment (isclose(x1, x2)) uses the line's y at x1 with the +-1e-9 bounds check
     assert run(1.0, 0.0, [1.0, 1.0, 2.0], [2.0, 0.0, 0.0]) == (1.0, 1.0)
+
+
+def test_numpy_port_vs_reference():
+    """The second, independently written checker (oracle/rt_numpy.py) against the same goldens."""
+    from oracle import rt_numpy
+    g = load_golden("compare_cfg.npz")
+    _check8(rt_numpy.shoot(0.0, D_PLANE, g["zf"], g["alpha"], 0.037, 0.0038), g["out8"], "numpy/compare")
+    e = load_golden("edge_cfg.npz")
+    for tag in ("q1nan", "tir", "off0", "offtx"):
+        r_o, off, x_tx = e[tag + "_cfg"]
+        _check8(rt_numpy.shoot(x_tx, D_PLANE, np.full(905, D_PLANE), e["alpha"], r_o, off), e[tag], "numpy/" + tag)
+    s = load_golden("sweep_cfg.npz")
+    for gi in range(0, 210, 13):
+        o = rt_numpy.shoot(0.0, D_PLANE, np.full(905, D_PLANE), s["alpha"], *s["geoms"][gi])
+        ref = s["target_x_tof"][gi]
+        assert nan_equal_mask(o[6], ref[0]) and max_abs(o[6], ref[0]) < 1e-11
+
+
+def test_lens_two_point_oracle_is_pinned_by_reference_rays():
+    """Fermat <=> Snell: golden-section minimiser (oracle) on (A, F = pipe point of a reference ray) gives
+    that ray's alpha and tof_1 + tof_2 (main_compare.py:514-515)."""
+    g = load_golden("compare_cfg.npz")
+    o, alpha, t4 = g["out8"], g["alpha"], g["tof4"]
+    idx = np.nonzero(np.isfinite(o[2]))[0][::9]
+    am = float(np.float64(50.62033040986099 * (np.pi / 180)))
+    tt, al = cport.tt_lens([0.0], [D_PLANE], o[2][idx], o[3][idx], -am, am)
+    assert np.max(np.abs(tt[0] - (t4[0] + t4[1])[idx])) < 1e-16
+    assert np.max(np.abs(al[0] - alpha[idx])) < 1e-8
