@@ -13,7 +13,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
                              void* ws, hipStream_t s);
 hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batch, int n, const double* x_rx,
-                             int n_rx, double atol, double rtol, int sorted, double win, int32_t* first_ray,
+                             int n_rx, double atol, double rtol, int32_t* first_ray,
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s);
 hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
@@ -174,11 +174,10 @@ static int check_match(const void* land_x, int n_batch, int n_rays, const void* 
 {
     if (!land_x || !x_rx || n_batch <= 0 || n_rays <= 0 || n_rx <= 0) return RTUS_ERR_INVALID_ARG;
     if (!(atol >= 0) || !(rtol >= 0)) return RTUS_ERR_INVALID_ARG;
-    if (n_batch > 65535 || n_rx > 4096) return RTUS_ERR_UNSUPPORTED;   // x_rx + tolerances live in 64 KiB of LDS
+    if (n_batch > 65535 || n_rx > 4000) return RTUS_ERR_UNSUPPORTED;   // x_rx + tolerances live in < 64 KiB of LDS
     return RTUS_OK;
 }
 
-// The device twin cannot inspect x_rx without a sync: it always runs the order-agnostic scan.
 int rtus_match_dev(const double* d_land_x, const double* d_tof, int n_batch, int n_rays, const double* d_x_rx,
                    int n_rx, double atol, double rtol, int32_t* d_first_ray, uint8_t* d_hit, double* d_tof_hit,
                    void* stream)
@@ -186,7 +185,7 @@ int rtus_match_dev(const double* d_land_x, const double* d_tof, int n_batch, int
     int st = check_match(d_land_x, n_batch, n_rays, d_x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!d_first_ray) return RTUS_ERR_INVALID_ARG;
-    HIP_TRY(rtus_launch_match(d_land_x, d_tof, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, 0, 0.0, d_first_ray,
+    HIP_TRY(rtus_launch_match(d_land_x, d_tof, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, d_first_ray,
                               d_hit, d_tof_hit, nullptr, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -197,23 +196,9 @@ int rtus_ray_hits_dev(const double* d_land_x, int n_batch, int n_rays, const dou
     int st = check_match(d_land_x, n_batch, n_rays, d_x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!d_ray_hit) return RTUS_ERR_INVALID_ARG;
-    HIP_TRY(rtus_launch_match(d_land_x, nullptr, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, 0, 0.0, nullptr,
+    HIP_TRY(rtus_launch_match(d_land_x, nullptr, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, nullptr,
                               nullptr, nullptr, d_ray_hit, (hipStream_t)stream));
     return RTUS_OK;
-}
-
-// host helper: ascending x_rx enables the binary-search window
-static int rx_sorted(const double* x_rx, int n_rx, double atol, double rtol, double* win)
-{
-    double amax = 0;
-    int sorted = 1;
-    for (int e = 0; e < n_rx; ++e) {
-        if (!isfinite(x_rx[e])) sorted = 0;
-        if (e && !(x_rx[e] >= x_rx[e - 1])) sorted = 0;
-        amax = fmax(amax, fabs(x_rx[e]));
-    }
-    *win = atol + rtol * amax;
-    return sorted && isfinite(*win);
 }
 
 int rtus_match(const double* land_x, const double* tof, int n_batch, int n_rays, const double* x_rx, int n_rx,
@@ -224,8 +209,6 @@ int rtus_match(const double* land_x, const double* tof, int n_batch, int n_rays,
     if (tof_hit && !tof) return RTUS_ERR_INVALID_ARG;
     if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays, re = (size_t)n_batch * n_rx;
-    double win = 0;
-    const int sorted = rx_sorted(x_rx, n_rx, atol, rtol, &win);
     DevBuf lx, tf, rx, fr, hb, th;
     HIP_TRY(lx.upload(land_x, sizeof(double) * rn));
     if (tof) HIP_TRY(tf.upload(tof, sizeof(double) * rn));
@@ -234,7 +217,7 @@ int rtus_match(const double* land_x, const double* tof, int n_batch, int n_rays,
     if (hit) HIP_TRY(hb.alloc(re));
     if (tof_hit) HIP_TRY(th.alloc(sizeof(double) * re));
     HIP_TRY(rtus_launch_match(lx.as<double>(), tf.as<double>(), n_batch, n_rays, rx.as<double>(), n_rx, atol,
-                              rtol, sorted, win, fr.as<int32_t>(), hb.as<uint8_t>(), th.as<double>(), nullptr, 0));
+                              rtol, fr.as<int32_t>(), hb.as<uint8_t>(), th.as<double>(), nullptr, 0));
     HIP_TRY(hipStreamSynchronize(0));
     if (first_ray) HIP_TRY(hipMemcpy(first_ray, fr.p, sizeof(int32_t) * re, hipMemcpyDeviceToHost));
     if (hit) HIP_TRY(hipMemcpy(hit, hb.p, re, hipMemcpyDeviceToHost));
@@ -250,14 +233,12 @@ int rtus_ray_hits(const double* land_x, int n_batch, int n_rays, const double* x
     if (!ray_hit) return RTUS_ERR_INVALID_ARG;
     if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays;
-    double win = 0;
-    const int sorted = rx_sorted(x_rx, n_rx, atol, rtol, &win);
     DevBuf lx, rx, rh;
     HIP_TRY(lx.upload(land_x, sizeof(double) * rn));
     HIP_TRY(rx.upload(x_rx, sizeof(double) * n_rx));
     HIP_TRY(rh.alloc(rn));
     HIP_TRY(rtus_launch_match(lx.as<double>(), nullptr, n_batch, n_rays, rx.as<double>(), n_rx, atol, rtol,
-                              sorted, win, nullptr, nullptr, nullptr, rh.as<uint8_t>(), 0));
+                              nullptr, nullptr, nullptr, rh.as<uint8_t>(), 0));
     HIP_TRY(hipStreamSynchronize(0));
     HIP_TRY(hipMemcpy(ray_hit, rh.p, rn, hipMemcpyDeviceToHost));
     return RTUS_OK;

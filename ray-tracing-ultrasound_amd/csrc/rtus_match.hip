@@ -16,22 +16,33 @@ struct MatchArgs {
     uint8_t* __restrict__ ray_hit;      // [n_batch][n]      nullable for match
     double atol, rtol;
     int n, n_rx, n_batch;
-    int sorted;                         // x_rx ascending -> binary search window
-    double win;                         // atol + rtol*max|x_rx| (search window, sorted mode)
 };
 
 // Workgroup = 256 rays of one batch row.  LDS: x_rx[n_rx] then tol[n_rx] (dynamic).
+// While staging the aperture the workgroup also finds out whether x_rx is ascending (arrays are):
+// then each ray binary-searches the window [x - win, x + win], win = atol + rtol*max|x_rx|, instead
+// of testing every element.  Any other order falls back to the full scan — same result either way.
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
 {
     extern __shared__ double lds[];
+    __shared__ double s_amax[RTUS_BLOCK / 64];
     double* sx = lds;
     double* stol = lds + a.n_rx;
+    bool asc = true;
+    double amax = 0.0;
     for (int e = threadIdx.x; e < a.n_rx; e += RTUS_BLOCK) {
         const double xe = a.x_rx[e];
         sx[e] = xe;
         stol[e] = a.atol + a.rtol * fabs(xe);      // np.isclose: atol + rtol*|b|, b = elem_x
+        asc = asc && isfinite(xe) && (e == 0 || a.x_rx[e - 1] <= xe);
+        amax = fmax(amax, fabs(xe));
     }
-    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = amax;
+    const bool sorted = __syncthreads_and(asc);    // also publishes sx / stol / s_amax
+    amax = fmax(fmax(s_amax[0], s_amax[1]), fmax(s_amax[2], s_amax[3]));
+    const double win = a.atol + a.rtol * amax;
 
     const int r = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const int row = blockIdx.y;
@@ -40,15 +51,15 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
     bool any = false;
     if (isfinite(x)) {                             // NaN / inf never match a finite element
         int e0 = 0, e1 = a.n_rx;
-        if (a.sorted) {                            // lower_bound(x - win)
-            const double lo = x - a.win;
+        if (sorted) {                              // lower_bound(x - win)
+            const double lo = x - win;
             int l = 0, h = a.n_rx;
             while (l < h) { const int mid = (l + h) >> 1; if (sx[mid] < lo) l = mid + 1; else h = mid; }
             e0 = l;
         }
         for (int e = e0; e < e1; ++e) {
             const double xe = sx[e];
-            if (a.sorted && xe > x + a.win) break;
+            if (sorted && xe > x + win) break;
             if (fabs(x - xe) <= stol[e]) {
                 any = true;
                 if (a.first_ray) atomicMin(&a.first_ray[(size_t)row * a.n_rx + e], r);
@@ -77,13 +88,12 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_finalize_kernel(int32_t
 }
 
 hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batch, int n, const double* x_rx,
-                             int n_rx, double atol, double rtol, int sorted, double win, int32_t* first_ray,
+                             int n_rx, double atol, double rtol, int32_t* first_ray,
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s)
 {
     MatchArgs a;
     a.land_x = land_x; a.x_rx = x_rx; a.first_ray = first_ray; a.ray_hit = ray_hit;
     a.atol = atol; a.rtol = rtol; a.n = n; a.n_rx = n_rx; a.n_batch = n_batch;
-    a.sorted = sorted; a.win = win;
     const size_t lds = (size_t)n_rx * 2 * sizeof(double);
     if (first_ray) {
         hipError_t e = hipMemsetAsync(first_ray, 0x7f, (size_t)n_batch * n_rx * sizeof(int32_t), s);
