@@ -84,19 +84,27 @@ int rtus_device_count(int *count);
  *   land_x  [n_geom][n_tx][n_rays]      nullable  (= out8 slot RTUS_TARGET_X alone)
  *   status  [n_geom][n_tx][n_rays]      nullable  RTUS_RAY_* bits
  * ---------------------------------------------------------------------------------------- */
+/* flags for rtus_shoot*:
+ *   0                     reference-compatible arithmetic: the reference's angle form (atan2 / asin / tan),
+ *                         operation for operation, no FMA contraction — reproduces even its rounding-decided rays.
+ *   RTUS_SHOOT_FAST_MATH  the same laws in vector form (no trigonometry): ~1e-15 relative from the above on
+ *                         regular rays, may differ on degenerate ones (exactly vertical / tangent rays). */
+#define RTUS_SHOOT_FAST_MATH 0x1u
+
 size_t rtus_shoot_workspace_bytes(int n_rays);
 
 int rtus_shoot_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,
                    const double *d_x_a, const double *d_z_a, int n_tx,
                    const double *d_alpha, const double *d_z_f, int n_rays,
                    double *d_out8, double *d_tof4, double *d_tof, double *d_land_x,
-                   uint8_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream);
+                   uint8_t *d_status, void *d_workspace, size_t workspace_bytes, unsigned flags,
+                   void *stream);
 
 int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
                const double *x_a, const double *z_a, int n_tx,
                const double *alpha, const double *z_f, int n_rays,
                double *out8, double *tof4, double *tof, double *land_x, uint8_t *status,
-               int device);
+               unsigned flags, int device);
 
 /* ------------------------------------------------------------------------------------------
  * Element matcher — replaces the scan of main_rt.py:487-501: for each receive element the FIRST

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtus.so")
+LIB_PATH = os.environ.get("RTUS_LIB") or os.path.join(HERE, "librtus.so")   # RTUS_LIB: experiment builds only
 CSRC = os.path.join(HERE, "csrc")
 
 _lib = None
@@ -69,8 +69,8 @@ def lib():
     L.rtus_shoot_workspace_bytes.argtypes = [ip]
     L.rtus_shoot_workspace_bytes.restype = C.c_size_t
     LP = C.POINTER(Lens)
-    L.rtus_shoot_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, vp, C.c_size_t, vp]
-    L.rtus_shoot.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, ip]
+    L.rtus_shoot_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, vp, C.c_size_t, C.c_uint, vp]
+    L.rtus_shoot.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, C.c_uint, ip]
     L.rtus_match_dev.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, vp]
     L.rtus_match.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, ip]
     L.rtus_ray_hits_dev.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp]

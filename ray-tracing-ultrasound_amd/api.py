@@ -87,11 +87,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
-def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want=("out8",), device=0):
+SHOOT_FAST_MATH = 0x1   # RTUS_SHOOT_FAST_MATH
+
+
+def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want=("out8",), fast=False,
+                device=0):
     """Forward trace for n_geom geometries x n_tx transmit points in ONE launch.
 
     geoms: [n_geom, 2] of (r_outer, pipe_offset); default = the one geometry in ``params``.
     want:  any of "out8" [G,T,8,N], "tof4" [G,T,4,N], "tof" [G,T,N], "land_x" [G,T,N], "status".
+    fast:  vector-form arithmetic (no trigonometry, ~3x faster); the default reproduces the reference's
+           angle-form arithmetic operation for operation.
     """
     p = _resolve(params)
     x_a, z_a = _f64(x_a, "x_a"), _f64(z_a, "z_a")
@@ -116,7 +122,7 @@ def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want
     lens = p.lens()
     st = _lib.lib().rtus_shoot(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), _ptr(z_f), N,
                                _ptr(bufs["out8"]), _ptr(bufs["tof4"]), _ptr(bufs["tof"]), _ptr(bufs["land_x"]),
-                               _ptr(bufs["status"]), int(device))
+                               _ptr(bufs["status"]), SHOOT_FAST_MATH if fast else 0, int(device))
     _lib.check(st, "rtus_shoot")
     return {w: bufs[w] for w in want}
 

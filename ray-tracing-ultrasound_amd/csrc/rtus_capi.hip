@@ -11,7 +11,7 @@ size_t rtus_ws_bytes(int n);
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
-                             void* ws, hipStream_t s);
+                             void* ws, unsigned flags, hipStream_t s);
 hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batch, int n, const double* x_rx,
                              int n_rx, double atol, double rtol, int32_t* first_ray,
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s);
@@ -122,26 +122,29 @@ static int check_shoot(const rtus_lens* lens, const void* geoms, int n_geom, con
     if (!(lens->c1 > 0) || !(lens->c2 > 0) || lens->c1 == lens->c2) return RTUS_ERR_INVALID_ARG;
     return RTUS_OK;
 }
+#define RTUS_SHOOT_KNOWN_FLAGS (RTUS_SHOOT_FAST_MATH)
 
 int rtus_shoot_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, const double* d_x_a,
                    const double* d_z_a, int n_tx, const double* d_alpha, const double* d_z_f, int n_rays,
                    double* d_out8, double* d_tof4, double* d_tof, double* d_land_x, uint8_t* d_status,
-                   void* d_workspace, size_t workspace_bytes, void* stream)
+                   void* d_workspace, size_t workspace_bytes, unsigned flags, void* stream)
 {
     int st = check_shoot(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays);
     if (st) return st;
+    if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
     if (!d_workspace || workspace_bytes < rtus_ws_bytes(n_rays)) return RTUS_ERR_WORKSPACE;
     HIP_TRY(rtus_launch_shoot(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_out8,
-                              d_tof4, d_tof, d_land_x, d_status, d_workspace, (hipStream_t)stream));
+                              d_tof4, d_tof, d_land_x, d_status, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;
 }
 
 int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const double* x_a, const double* z_a,
                int n_tx, const double* alpha, const double* z_f, int n_rays, double* out8, double* tof4,
-               double* tof, double* land_x, uint8_t* status, int device)
+               double* tof, double* land_x, uint8_t* status, unsigned flags, int device)
 {
     int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f, n_rays);
     if (st) return st;
+    if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
     if ((st = select_device(device))) return st;
     const size_t rows = (size_t)n_geom * n_tx, n = (size_t)n_rays;
     DevBuf g, xa, za, al, zf, ws, o8, t4, tt, lx, sb;
@@ -158,7 +161,7 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     if (status) HIP_TRY(sb.alloc(rows * n));
     HIP_TRY(rtus_launch_shoot(*lens, g.as<double>(), n_geom, xa.as<double>(), za.as<double>(), n_tx,
                               al.as<double>(), zf.as<double>(), n_rays, o8.as<double>(), t4.as<double>(),
-                              tt.as<double>(), lx.as<double>(), sb.as<uint8_t>(), ws.p, 0));
+                              tt.as<double>(), lx.as<double>(), sb.as<uint8_t>(), ws.p, flags, 0));
     HIP_TRY(hipStreamSynchronize(0));
     if (out8) HIP_TRY(hipMemcpy(out8, o8.p, sizeof(double) * rows * 8 * n, hipMemcpyDeviceToHost));
     if (tof4) HIP_TRY(hipMemcpy(tof4, t4.p, sizeof(double) * rows * 4 * n, hipMemcpyDeviceToHost));

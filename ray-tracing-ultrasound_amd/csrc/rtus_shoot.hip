@@ -4,6 +4,7 @@
 // Layout in HBM (workspace, built once per call by rtus_curve_kernel; shared by every tx / geometry)
 //   curve   double2[n]        (x_p, z_p) of the alpha grid
 //   phi_s   double[n]         atan2(dz, dx) of the lens tangent at alpha[j]
+//   tan_u   double2[n]        the same tangent as a unit vector (fast-math mode)
 //   node0   double4[n/8]      bounding box (xc, xh, zc, zh = centre / half-extent) of 8 polyline points
 //   node1   double4[n/64]     ... of 64 points
 //   node2   double4[n/512]    ... of 512 points
@@ -30,6 +31,7 @@ struct ShootArgs {
     const double* __restrict__ z_f;     // [n]
     const double2* __restrict__ curve;  // [n]
     const double* __restrict__ phi_s;   // [n]
+    const double2* __restrict__ tan_u;  // [n] unit tangent (cos phi_s, sin phi_s)
     const double4* __restrict__ node0;  // [n0]
     const double4* __restrict__ node1;  // [n1]
     const double4* __restrict__ node2;  // [n2]
@@ -53,6 +55,7 @@ __device__ __forceinline__ double4 make_box(double xmin, double xmax, double zmi
 __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, const double* __restrict__ alpha,
                                                                      int n, double2* __restrict__ curve,
                                                                      double* __restrict__ phi_s,
+                                                                     double2* __restrict__ tan_u,
                                                                      double4* __restrict__ node0,
                                                                      double4* __restrict__ node1,
                                                                      double4* __restrict__ node2)
@@ -64,7 +67,10 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
     if (live) {
         lens_eval(k, alpha[j], x, z, dz, dx);       // main_rt.py:338, 344
         curve[j] = make_double2(x, z);
+        if (j == n - 1) for (int q = n; q < ((n + 7) & ~7); ++q) curve[q] = make_double2(x, z);   // leaf padding
         phi_s[j] = atan2(dz, dx);                   // main_rt.py:272 (tuple branch of refraction)
+        const double rt = 1.0 / sqrt(dx * dx + dz * dz);
+        tan_u[j] = make_double2(dx * rt, dz * rt);
     }
     double xmin = live ? x : INFINITY, xmax = live ? x : -INFINITY;
     double zmin = live ? z : INFINITY, zmax = live ? z : -INFINITY;
@@ -91,32 +97,61 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
     }
 }
 
-// Per-lane line + search state for the lock-step walk.
-struct LineState {
-    double m, b, am, marg;   // line z = m x + b; |m|; certification margin
-    bool found;              // first sign change located (or the line is non-finite: nothing to find)
-    int idx;                 // its index (segment idx .. idx+1), -1 if none
-    int pcls;                // class of the previous polyline point: -1 / 0 / +1, 2 = no point seen yet
+// Crossing search state.  The reference wants the first j with sign(d_j) != sign(d_{j+1})
+// (main_rt.py:82, 99).  Every point before that change has the class c0 = np.sign(d_0) of polyline
+// point 0, so equivalently: p = the first polyline point whose class differs from c0, idx = p - 1.
+// Everything that is one bit per ray lives in 64-bit lane masks (SGPR pairs): v_cmp writes them
+// directly and the bookkeeping is scalar-ALU work.
+typedef unsigned long long lanemask;
+#ifdef RTUS_EXP_COUNT
+__device__ unsigned long long rtus_dbg[8];
+#define DBG(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&rtus_dbg[i], 1ull); } while (0)
+#else
+#define DBG(i) do {} while (0)
+#endif
+
+struct Walk {
+    double m, b, am, marg;   // per lane: line z = m x + b, |m|, certification margin
+    int idx;                 // per lane: p - 1 (segment idx .. idx+1 holds the first sign change), -1 if none
+    int leaf;                // per lane: 8-point leaf the lane still has to look into
+    int start;               // per lane: polyline points before this index are known to have class c0
+    lanemask c0pos, c0neg;   // class of polyline point 0 per ray (neither bit: d_0 == 0)
+    lanemask found;          // rays that are resolved: p located, or nothing left to look at
+    lanemask pend;           // rays parked on `leaf`
 };
 
-// Is the whole box on one side of the line?  +1: every d_j > 0, -1: every d_j < 0, 0: cannot tell.
-__device__ __forceinline__ int certify(const LineState& L, const double4 bx)
+__device__ __forceinline__ bool lane_bit(lanemask m) { return (m >> (threadIdx.x & 63)) & 1ull; }
+
+// Which rays have the whole box on one side of their line?  pos: every d_j > 0, neg: every d_j < 0.
+__device__ __forceinline__ void certify(const Walk& W, const double4 bx, lanemask& pos, lanemask& neg)
 {
-    const double e = bx.z - fma(L.m, bx.x, L.b);         // d at the box centre
-    const double s = fma(L.am, bx.y, bx.w) + L.marg;     // how far d can move inside the box + margin
-    return e > s ? 1 : (e < -s ? -1 : 0);
+    const double e = bx.z - fma(W.m, bx.x, W.b);         // d at the box centre
+    const double s = fma(W.am, bx.y, bx.w) + W.marg;     // how far d can move inside the box + margin
+    pos = __ballot(e > s);
+    neg = __ballot(e < -s);
 }
 
-// A certified box: all its points have class c.  A change against the previous point is a hit at j0-1.
-__device__ __forceinline__ void pass_box(LineState& L, int c, int j0)
+// Visit the box whose first polyline point is j0 (and, on a retry pass, whose last is j1 - 1).
+// Returns the mask of active rays that could not be decided at this box.
+__device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int j1, bool retry, lanemask all)
 {
-    if (!L.found) {
-        if (L.pcls != 2 && L.pcls != c) { L.found = true; L.idx = j0 - 1; }
-        L.pcls = c;
+    lanemask pos, neg;
+    certify(W, bx, pos, neg);
+    lanemask same = (pos & W.c0pos) | (neg & W.c0neg);                   // all points still class c0
+    lanemask unsure = ~(pos | neg);
+    if (retry) {                                                          // points before `start` are known c0
+        const lanemask before = __ballot(j1 <= W.start), partly = __ballot(j0 < W.start) & ~before;
+        same |= before; unsure = (unsure | partly) & ~before;
     }
+    const lanemask active = all & ~(W.found | W.pend);
+    const lanemask diff = active & ~same & ~unsure;                      // certified, and not class c0: p = j0
+    W.found |= diff;
+    W.idx = lane_bit(diff) ? j0 - 1 : W.idx;
+    return active & unsure;
 }
 
 // ---- the forward trace -----------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 {
     const int n = a.n;
@@ -131,10 +166,25 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 
     // --- element -> lens, refraction lens -> water (main_rt.py:338-349) -----------------------
     const double2 P = a.curve[r];
-    const double phis = a.phi_s[r];
-    const double phi_ap = atan2(za - P.y, xa - P.x);                   // :341
-    const double phi_pq = refract_angle(phi_ap, phis, k.c2 / k.c1);   // :345
-    const double a_pq = tan(phi_pq);                                   // :348
+    double a_pq, ux = 0.0, uz = 0.0;               // slope of the refracted line; FAST: its unit direction
+    double phi_pq = 0.0;
+    if (!FAST) {
+        const double phis = a.phi_s[r];
+        const double phi_ap = atan2(za - P.y, xa - P.x);               // :341
+        phi_pq = refract_angle(phi_ap, phis, k.c2 / k.c1);             // :345
+        a_pq = tan(phi_pq);                                            // :348
+    } else {
+        // Same law without angles.  With t = unit tangent, n = (-tz, tx), v = unit(A - P):
+        // sin(theta_1) = sin(phi_ap - phi_n) = -(t.v); theta_2 = asin(eta sin theta_1) (|.|>1 -> NaN = TIR);
+        // direction at phi_pq = phi_s - pi/2 + theta_2 is  u = -n cos(theta_2) + t sin(theta_2).
+        const double2 t = a.tan_u[r];
+        const double vx = xa - P.x, vz = za - P.y;
+        const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) / sqrt(vx * vx + vz * vz);
+        const double c2 = sqrt(1.0 - s2 * s2);
+        ux = t.y * c2 + t.x * s2;
+        uz = -t.x * c2 + t.y * s2;
+        a_pq = uz / ux;
+    }
     const double b_pq = P.y - a_pq * P.x;                              // :349
 
     // --- line ∩ circle, keep the upper root (main_rt.py:351-364) ------------------------------
@@ -150,9 +200,18 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 
     // --- reflection on the pipe (main_rt.py:367-376); tangent ignores pipe_offset --
     const double slope = -xq / sqrt(r_outer * r_outer - xq * xq);      // :237-238
-    const double phi_sl = atan(slope);                                 // :287
-    const double phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));   // :289-291
-    const double m = tan(phi_l);                                       // :375
+    double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
+    if (!FAST) {
+        const double phi_sl = atan(slope);                             // :287
+        phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));  // :289-291
+        m = tan(phi_l);                                                // :375
+    } else {
+        // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
+        const double s_2 = slope * slope, inv = 1.0 / (1.0 + s_2);
+        lx_u = ((1.0 - s_2) * ux + 2.0 * slope * uz) * inv;
+        lz_u = (2.0 * slope * ux - (1.0 - s_2) * uz) * inv;
+        m = lz_u / lx_u;
+    }
     const double b = zq - m * xq;                                      // :376
 
     // --- first sign change of d_j along the polyline (main_rt.py:78-99) -----------------------
@@ -164,64 +223,106 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         xabs = fmax(xabs, fabs(bx.x) + bx.y);
         zabs = fmax(zabs, fabs(bx.z) + bx.w);
     }
-    LineState L;
-    L.m = m; L.b = b; L.am = fabs(m);
+    Walk W;
+    W.m = m; W.b = b; W.am = fabs(m);
     // 2e-8 >= the reference's isclose(d, 0) atol, so a skipped box can hold no "point on the line"
     // (main_rt.py:86); the relative part is ~450x the worst fp64 rounding of d_j.
-    L.marg = 2e-8 + 1e-13 * (fma(L.am, xabs, fabs(b)) + zabs);
-    L.found = !fin; L.idx = -1; L.pcls = 2;
-
-    for (int S = 0; S < a.n2; ++S) {
-        if (__all(L.found)) break;
-        const int c2 = certify(L, a.node2[S]);                         // wave-uniform index -> scalar load
-        if (!__any(!L.found && c2 == 0)) { pass_box(L, c2, S * 512); continue; }
-        const int B1 = min(S * 8 + 8, a.n1);
-        for (int B = S * 8; B < B1; ++B) {
-            const int c1 = certify(L, a.node1[B]);
-            if (!__any(!L.found && c1 == 0)) { pass_box(L, c1, B * 64); continue; }
-            const int U1 = min(B * 8 + 8, a.n0);
-            for (int U = B * 8; U < U1; ++U) {
-                const int c0 = certify(L, a.node0[U]);
-                if (!__any(!L.found && c0 == 0)) { pass_box(L, c0, U * 8); continue; }
-                const int j1 = min(U * 8 + 8, n);
-                for (int j = U * 8; j < j1; ++j) {                      // leaf: point by point
-                    const double2 c = a.curve[j];
-                    const double t = fma(m, c.x, b);
-                    const int cls = (c.y > t) - (c.y < t);             // np.sign(d_j)
-                    if (!L.found && L.pcls != 2 && cls != L.pcls) { L.found = true; L.idx = j - 1; }
-                    L.pcls = cls;
+    W.marg = 2e-8 + 1e-13 * (fma(W.am, xabs, fabs(b)) + zabs);
+    W.idx = -1; W.leaf = 0; W.start = 0; W.pend = 0;
+    const lanemask all = __ballot(true);
+    W.found = __ballot(!fin);                      // non-finite lines: nothing to find
+    {
+        const double2 c0 = a.curve[0];
+        const double t0 = fma(m, c0.x, b);
+        W.c0pos = __ballot(c0.y > t0); W.c0neg = __ballot(c0.y < t0);   // np.sign(d_0)
+    }
+#ifdef RTUS_EXP_NOSCAN   // timing experiment only: pretend every ray crosses at its own index
+    W.found = ~0ull; W.idx = min(r, n - 2);
+#endif
+    // Lock-step part: boxes are visited in index order with wave-uniform indices (scalar loads); a ray
+    // leaves the walk when a box certifies its answer or when it reaches an 8-point leaf it cannot
+    // decide — that leaf it then reads itself (per-lane gather), so the wave never evaluates the
+    // union of all 64 rays' leaves point by point.
+    for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
+        const bool retry = pass > 0;
+        for (int S = 0; S < a.n2 && (all & ~(W.found | W.pend)); ++S) {
+            DBG(0);
+            if (!visit(W, a.node2[S], S * 512, S * 512 + 512, retry, all)) continue;
+            const int B1 = min(S * 8 + 8, a.n1);
+            for (int B = S * 8; B < B1 && (all & ~(W.found | W.pend)); ++B) {
+                DBG(1);
+                if (!visit(W, a.node1[B], B * 64, B * 64 + 64, retry, all)) continue;
+                const int U1 = min(B * 8 + 8, a.n0);
+                for (int U = B * 8; U < U1; ++U) {
+                    DBG(2);
+                    const lanemask park = visit(W, a.node0[U], U * 8, U * 8 + 8, retry, all);
+                    W.pend |= park;
+                    W.leaf = lane_bit(park) ? U : W.leaf;
                 }
             }
         }
+        W.found |= all & ~W.pend;                   // walked off the end: no class change anywhere
+        if (!W.pend) break;
+        DBG(3);
+        // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
+        // point: a copy never changes class, so the padding cannot produce a hit).
+        const bool mine = lane_bit(W.pend), cp0 = lane_bit(W.c0pos), cn0 = lane_bit(W.c0neg);
+        const double2* __restrict__ cp = a.curve + (size_t)W.leaf * 8;
+        int hit = -1;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            const double2 c = cp[i];
+            const double t = fma(m, c.x, b);
+            const bool differs = cp0 ? !(c.y > t) : (cn0 ? !(c.y < t) : (c.y != t));   // np.sign(d_j) != c0
+            hit = differs ? i : hit;
+        }
+        const bool got = mine && hit >= 0;
+        W.idx = got ? W.leaf * 8 + hit - 1 : W.idx;
+        W.found |= __ballot(got);
+        W.start = (mine && !got) ? W.leaf * 8 + 8 : W.start;             // nothing here: resume after this leaf
+        W.found &= ~__ballot(mine && !got);
+        W.pend = 0;
+        if ((W.found & all) == all) break;
     }
-    const int idx = L.idx;
+    const int idx = W.idx;
 
     double xi = NAN, zi = NAN;
     // No sign change anywhere: first polyline point within isclose(d, 0) of the line, else None
     // (main_rt.py:84-96).  Such a point can only sit in a box the line could not be certified
     // against, so the same walk finds it; lines that miss the lens by a clear margin cost only
     // the top-level box tests.
-    const bool need_on = fin && idx < 0;
-    if (__any(need_on)) {
-        int on = 0x7fffffff;
+    const lanemask need_on = __ballot(fin && idx < 0);
+    if (need_on) {
+        DBG(4);
+        lanemask on_found = 0;
+        int on = -1;
         for (int S = 0; S < a.n2; ++S) {
-            if (!__any(need_on && certify(L, a.node2[S]) == 0)) continue;
+            lanemask pos, neg;
+            certify(W, a.node2[S], pos, neg);
+            DBG(5);
+            if (!(need_on & ~(pos | neg))) continue;
             const int B1 = min(S * 8 + 8, a.n1);
             for (int B = S * 8; B < B1; ++B) {
-                if (!__any(need_on && certify(L, a.node1[B]) == 0)) continue;
+                certify(W, a.node1[B], pos, neg);
+                if (!(need_on & ~(pos | neg))) continue;
                 const int U1 = min(B * 8 + 8, a.n0);
                 for (int U = B * 8; U < U1; ++U) {
-                    if (!__any(need_on && certify(L, a.node0[U]) == 0)) continue;
+                    certify(W, a.node0[U], pos, neg);
+                    DBG(6);
+                    if (!(need_on & ~(pos | neg))) continue;
+                    DBG(7);
                     const int j1 = min(U * 8 + 8, n);
                     for (int j = U * 8; j < j1; ++j) {
                         const double2 c = a.curve[j];
                         const double dj = c.y - (m * c.x + b);        // :78-79, NumPy rounding
-                        if (fabs(dj) <= 1e-8) on = min(on, j);         // :86 isclose(diffs, 0)
+                        const lanemask hit = __ballot(fabs(dj) <= 1e-8) & ~on_found;   // :86 isclose(diffs, 0)
+                        on_found |= hit;
+                        on = ((hit >> (threadIdx.x & 63)) & 1ull) ? j : on;
                     }
                 }
             }
         }
-        if (need_on && on != 0x7fffffff) { const double2 c = a.curve[on]; xi = c.x; zi = c.y; }   // :88-90
+        if (fin && idx < 0 && on >= 0) { const double2 c = a.curve[on]; xi = c.x; zi = c.y; }   // :88-90
     }
     if (idx >= 0) {                                                    // main_rt.py:106-168
         const double2 c1p = a.curve[idx], c2p = a.curve[idx + 1];
@@ -247,11 +348,29 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
     }
 
     // --- refraction water -> lens and landing on z = z_f (main_rt.py:396-405) ------------------
-    const double alpha_i = atan2(xi, zi);                              // :396
-    double lx, lz, ldz, ldx;
-    lens_eval(k, alpha_i, lx, lz, ldz, ldx);                           // :397 (analytic tangent at the chord point's polar angle)
-    const double phi_last = refract_angle(phi_l, atan2(ldz, ldx), k.c1 / k.c2);   // :398
-    const double a3 = tan(phi_last);                                   // :401
+    double a3;
+    if (!FAST) {
+        const double alpha_i = atan2(xi, zi);                          // :396
+        double lx, lz, ldz, ldx;
+        lens_eval(k, alpha_i, lx, lz, ldz, ldx);                       // :397 (analytic tangent at the chord point's polar angle)
+        const double phi_last = refract_angle(phi_l, atan2(ldz, ldx), k.c1 / k.c2);   // :398
+        a3 = tan(phi_last);                                            // :401
+    } else {
+        // sin / cos of alpha_i = atan2(xi, zi) are xi/rho, zi/rho; then the refraction law as above.
+        const double rr = 1.0 / sqrt(xi * xi + zi * zi);
+        const double si = xi * rr, ci = zi * rr;
+        const double B = k.phi_3 * ci - k.twoTc;
+        const double sqd = sqrt(B * B - k.C4A);
+        const double h = (-B - sqd) / k.twoA;
+        const double dB = -k.phi_3 * si;
+        const double dh = k.phi_1 * (dB + B * dB / sqd);
+        double tz = dh * ci - h * si, tx_ = dh * si + h * ci;          // (dz, dx)
+        const double rt = 1.0 / sqrt(tx_ * tx_ + tz * tz);
+        tx_ *= rt; tz *= rt;
+        const double s2 = -(k.c1 / k.c2) * (tx_ * lx_u + tz * lz_u);   // u_l is a unit vector
+        const double c2 = sqrt(1.0 - s2 * s2);                         // NaN = total internal reflection
+        a3 = (-tx_ * c2 + tz * s2) / (tz * c2 + tx_ * s2);
+    }
     const double b3 = zi - a3 * xi;                                    // :402
     const double zf = a.z_f[r];
     const double x_in = (zf - b3) / a3;                                // :404
@@ -280,8 +399,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
 
 // ---- host-side launchers (called from rtus_capi.hip) -----------------------------------------
 static size_t align32(size_t v) { return (v + 31) & ~(size_t)31; }
-static size_t ws_phis_off(int n) { return align32((size_t)n * sizeof(double2)); }
-static size_t ws_node0_off(int n) { return align32(ws_phis_off(n) + (size_t)n * sizeof(double)); }
+static int pad8(int n) { return (n + 7) & ~7; }
+static size_t ws_phis_off(int n) { return align32((size_t)pad8(n) * sizeof(double2)); }
+static size_t ws_tanu_off(int n) { return align32(ws_phis_off(n) + (size_t)n * sizeof(double)); }
+static size_t ws_node0_off(int n) { return align32(ws_tanu_off(n) + (size_t)n * sizeof(double2)); }
 static size_t ws_node1_off(int n) { return ws_node0_off(n) + (size_t)((n + 7) / 8) * sizeof(double4); }
 static size_t ws_node2_off(int n) { return ws_node1_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
 size_t rtus_ws_bytes(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
@@ -289,7 +410,7 @@ size_t rtus_ws_bytes(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512)
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
-                             void* ws, hipStream_t s)
+                             void* ws, unsigned flags, hipStream_t s)
 {
     char* w = (char*)ws;
     ShootArgs a;
@@ -297,6 +418,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f;
     a.curve = (const double2*)w;
     a.phi_s = (const double*)(w + ws_phis_off(n));
+    a.tan_u = (const double2*)(w + ws_tanu_off(n));
     a.node0 = (const double4*)(w + ws_node0_off(n));
     a.node1 = (const double4*)(w + ws_node1_off(n));
     a.node2 = (const double4*)(w + ws_node2_off(n));
@@ -304,9 +426,20 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
-                       (double2*)a.curve, (double*)a.phi_s, (double4*)a.node0, (double4*)a.node1,
+                       (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
                        (double4*)a.node2);
-    hipLaunchKernelGGL(rtus_shoot_kernel, dim3((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom),
-                       dim3(RTUS_BLOCK), 0, s, a);
+    const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
+    if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_shoot_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(rtus_shoot_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, a);
     return hipGetLastError();
 }
+
+#ifdef RTUS_EXP_COUNT   // experiment builds only (scripts/exp_count.py)
+extern "C" int rtus_dbg_read(unsigned long long* out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(rtus_dbg), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(rtus_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif

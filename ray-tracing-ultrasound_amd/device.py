@@ -29,7 +29,7 @@ class ShootPlan:
     """Pre-allocated workspace + outputs for repeated forward traces of one shape (no allocation,
     no sync inside ``run`` — safe to capture in a hipGraph)."""
 
-    def __init__(self, n_geom, n_tx, n_rays, *, want=("out8",), params: Params = None, device="cuda"):
+    def __init__(self, n_geom, n_tx, n_rays, *, want=("out8",), params: Params = None, fast=False, device="cuda"):
         self.p = _resolve(params)
         self.G, self.T, self.N = int(n_geom), int(n_tx), int(n_rays)
         self.ws_bytes = int(_lib.lib().rtus_shoot_workspace_bytes(self.N))
@@ -39,6 +39,7 @@ class ShootPlan:
         self.out = {w: torch.empty(shapes[w], dtype=torch.uint8 if w == "status" else torch.float64, device=device)
                     for w in want}
         self.lens = self.p.lens()
+        self.flags = 1 if fast else 0
 
     def run(self, geoms, x_a, z_a, alpha, z_f):
         _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(z_f, "z_f")
@@ -49,7 +50,7 @@ class ShootPlan:
         st = _lib.lib().rtus_shoot_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha),
                                        _p(z_f), self.N, _p(o.get("out8")), _p(o.get("tof4")), _p(o.get("tof")),
                                        _p(o.get("land_x")), _p(o.get("status")), _p(self.ws), self.ws_bytes,
-                                       _stream())
+                                       self.flags, _stream())
         _lib.check(st, "rtus_shoot_dev")
         return o
 

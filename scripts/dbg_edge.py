@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rtus
 e=np.load('tests/golden/edge_cfg.npz')
 D=float(np.float64(0.12156646438729327)+np.float64(0.08843353561270673))

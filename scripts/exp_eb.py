@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rtus
 from importlib import import_module
 dev_api=import_module("ray-tracing-ultrasound_amd.device")

@@ -44,9 +44,10 @@ def test_invalid_arguments_are_status_codes_not_crashes(rtus):
     a = np.zeros(4)
     p = a.ctypes.data
     # curve needs >= 2 points (reference: ValueError main_rt.py:26-27)
-    assert L.rtus_shoot(C.byref(lens), p, 1, p, p, 1, p, p, 1, None, None, None, None, None, 0) == -1
-    assert L.rtus_shoot(None, p, 1, p, p, 1, p, p, 4, None, None, None, None, None, 0) == -1
-    assert L.rtus_shoot_dev(C.byref(lens), p, 1, p, p, 1, p, p, 4, None, None, None, None, None, None, 0, None) == -4
+    assert L.rtus_shoot(C.byref(lens), p, 1, p, p, 1, p, p, 1, None, None, None, None, None, 0, 0) == -1
+    assert L.rtus_shoot(None, p, 1, p, p, 1, p, p, 4, None, None, None, None, None, 0, 0) == -1
+    assert L.rtus_shoot(C.byref(lens), p, 1, p, p, 1, p, p, 4, None, None, None, None, None, 0x80, 0) == -1   # unknown flag
+    assert L.rtus_shoot_dev(C.byref(lens), p, 1, p, p, 1, p, p, 4, None, None, None, None, None, None, 0, 0, None) == -4
     assert L.rtus_match(p, p, 1, 4, p, 0, 1e-6, 1e-5, None, None, None, 0) == -1
     assert L.rtus_match(p, p, 1, 4, p, 5000, 1e-6, 1e-5, None, None, None, 0) == -5
     z = np.array([0.02, 0.01])                                  # not ascending

@@ -134,3 +134,46 @@ def test_matcher_vs_oracle(rtus):
                 assert np.array_equal(first[row], of)
                 assert np.array_equal(th[row], ot)
                 assert np.array_equal(rh[row], cport.ray_hits(land[row], xr, atol))
+
+
+def test_fast_math_mode_vs_reference(rtus):
+    """RTUS_SHOOT_FAST_MATH (vector-form laws, no trigonometry) against the same reference captures.
+    Stated tolerance for this mode: NaN masks identical on regular rays, |dx| < 1e-9 m, |dt| < 1e-12 s
+    (bar 1e-9 s).  Rays the reference itself decides by rounding noise (exactly vertical / tangent: the
+    alpha = 0 ray of the q1nan fixture) are excluded — that is what the default mode is for."""
+    g = load_golden("compare_cfg.npz")
+    p = rtus.Params(r_outer=float(g["r_outer"]), pipe_offset=float(g["pipe_offset"]))
+    b = rtus.shoot_batch([0.0], [D_PLANE], g["zf"], g["alpha"], params=p, want=("out8", "tof4"), fast=True)
+    o, t4 = b["out8"][0, 0], b["tof4"][0, 0]
+    for k in range(8):
+        assert nan_equal_mask(o[k], g["out8"][k])
+        assert max_abs(o[k], g["out8"][k]) < 1e-9
+    assert nan_equal_mask(t4, g["tof4"]) and max_abs(t4, g["tof4"]) < 1e-12
+    s = load_golden("sweep_cfg.npz")
+    zf = np.full(905, D_PLANE)
+    b = rtus.shoot_batch([0.0], [D_PLANE], zf, s["alpha"], s["geoms"], params=rtus.Params(),
+                         want=("tof", "land_x"), fast=True)
+    ref = s["target_x_tof"]
+    lx, tof = b["land_x"][:, 0], b["tof"][:, 0]
+    mid = np.zeros_like(lx, dtype=bool); mid[:, 452] = True          # alpha = 0: vertical ray (degenerate)
+    same = np.isnan(lx) == np.isnan(ref[:, 0])
+    assert same[~mid].all()
+    ok = ~np.isnan(ref[:, 0]) & ~np.isnan(lx) & ~mid
+    assert np.max(np.abs(lx - ref[:, 0])[ok]) < 1e-9
+    assert np.max(np.abs(tof - ref[:, 1])[ok]) < 1e-12
+    hit, tof_hit, _ = rtus.match_elements(lx, tof, s["x_elem"], atol=1e-6)
+    import csv, os
+    from conftest import GOLDEN
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "database_2.csv"))))[1:]
+    db_hit = np.array([r[3] == "True" for r in rows]).reshape(210, 65)
+    db_tof = np.array([float(r[4]) for r in rows]).reshape(210, 65)
+    assert (hit != db_hit).sum() <= 2                               # element hits sit on a 1e-6 m tolerance edge
+    both = hit & db_hit
+    assert np.max(np.abs(tof_hit - db_tof)[both]) < 1e-12
+    ga = load_golden("alltx_a.npz")
+    xe = ga["x_elem"]
+    b = rtus.shoot_batch(xe, np.full(xe.size, D_PLANE), zf, ga["alpha"],
+                         params=rtus.Params(r_outer=float(ga["r_outer"]), pipe_offset=float(ga["pipe_offset"])), fast=True)
+    for k in range(8):
+        assert nan_equal_mask(b["out8"][0, :, k], ga["out8"][:, k])
+        assert max_abs(b["out8"][0, :, k], ga["out8"][:, k]) < 1e-9
