@@ -180,7 +180,8 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: other threads (e.g. the RCCL watchdog at --gpus > 1) may keep issuing HIP calls
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for s in range(args.steps):
                         step(s)
             torch.cuda.current_stream().wait_stream(side)
