@@ -150,6 +150,14 @@ __device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int
     return active & unsure;
 }
 
+// Fast-math mode keeps lines in slope form like the reference does; an exactly vertical direction would
+// make the slope infinite where the reference gets tan(pi/2 rounded) = 1.633e16.  Same cap here.
+__device__ __forceinline__ double cap_vertical(double ux, double uz)
+{
+    const double lim = 6.123233995736766e-17 * fabs(uz);       // 1 / tan(fl(pi/2))
+    return fabs(ux) < lim ? copysign(lim, ux) : ux;           // NaN stays NaN
+}
+
 // ---- the forward trace -----------------------------------------------------------------------
 template <bool FAST>
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         const double vx = xa - P.x, vz = za - P.y;
         const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) / sqrt(vx * vx + vz * vz);
         const double c2 = sqrt(1.0 - s2 * s2);
-        ux = t.y * c2 + t.x * s2;
         uz = -t.x * c2 + t.y * s2;
+        ux = cap_vertical(t.y * c2 + t.x * s2, uz);
         a_pq = uz / ux;
     }
     const double b_pq = P.y - a_pq * P.x;                              // :349
@@ -208,8 +216,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
     } else {
         // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
         const double s_2 = slope * slope, inv = 1.0 / (1.0 + s_2);
-        lx_u = ((1.0 - s_2) * ux + 2.0 * slope * uz) * inv;
         lz_u = (2.0 * slope * ux - (1.0 - s_2) * uz) * inv;
+        lx_u = cap_vertical(((1.0 - s_2) * ux + 2.0 * slope * uz) * inv, lz_u);
         m = lz_u / lx_u;
     }
     const double b = zq - m * xq;                                      // :376
@@ -369,7 +377,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         tx_ *= rt; tz *= rt;
         const double s2 = -(k.c1 / k.c2) * (tx_ * lx_u + tz * lz_u);   // u_l is a unit vector
         const double c2 = sqrt(1.0 - s2 * s2);                         // NaN = total internal reflection
-        a3 = (-tx_ * c2 + tz * s2) / (tz * c2 + tx_ * s2);
+        const double w3z = -tx_ * c2 + tz * s2;
+        a3 = w3z / cap_vertical(tz * c2 + tx_ * s2, w3z);
     }
     const double b3 = zi - a3 * xi;                                    // :402
     const double zf = a.z_f[r];

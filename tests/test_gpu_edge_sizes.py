@@ -1,0 +1,69 @@
+"""GPU: size edge cases of the forward trace / matcher through the C ABI vs the C oracle —
+minimum curve (2 points), ray counts around the 8 / 64 / 512 box boundaries, one big polyline."""
+import numpy as np
+import pytest
+
+from conftest import D_PLANE, max_abs, nan_equal_mask
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 8, 9, 63, 64, 65, 511, 512, 513, 4097])
+def test_ray_counts_around_box_boundaries(rtus, n):
+    from oracle import cport
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    for fast in (False, True):
+        b = rtus.shoot_batch([0.0, -0.0123], [D_PLANE, D_PLANE], zf, alpha, [[0.037, 0.0038], [0.08, -0.006]],
+                             params=rtus.Params(), want=("out8", "status"), fast=fast)
+        for gi, (r_o, off) in enumerate([(0.037, 0.0038), (0.08, -0.006)]):
+            for t, xa in enumerate((0.0, -0.0123)):
+                o, st = cport.shoot(xa, D_PLANE, zf, alpha, r_o, off)
+                got = b["out8"][gi, t]
+                for k in range(8):
+                    assert nan_equal_mask(got[k], o[k]), (n, fast, gi, t, k)
+                    assert max_abs(got[k], o[k]) < (1e-9 if fast else 1e-12)
+                assert np.array_equal(b["status"][gi, t], st)
+
+
+def test_large_polyline_matches_oracle_on_subsample(rtus):
+    """N = 65,536 rays/polyline points (128 top-level boxes): every 97th ray vs the oracle's full O(N) scan."""
+    from oracle import cport
+    n = 65536
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    b = rtus.shoot_batch([0.004], [D_PLANE], zf, alpha, params=rtus.Params(r_outer=0.037, pipe_offset=0.0038),
+                         want=("out8", "tof"))
+    o, _ = cport.shoot(0.004, D_PLANE, zf, alpha, 0.037, 0.0038)
+    sel = slice(None, None, 97)
+    for k in range(8):
+        assert nan_equal_mask(b["out8"][0, 0, k], o[k])
+        assert max_abs(b["out8"][0, 0, k][sel], o[k][sel]) < 1e-12
+
+
+def test_miss_geometry_sets_status_instead_of_raising(rtus):
+    """Rays that miss the pipe: the reference raises LinAlgError; librtus returns NaN + status bit."""
+    n = 905
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    b = rtus.shoot_batch([0.0], [D_PLANE], np.full(n, D_PLANE), alpha, params=rtus.Params(r_outer=0.005, pipe_offset=0.05),
+                         want=("out8", "status", "tof"))
+    st = b["status"][0, 0].astype(bool)
+    assert st.any()
+    assert np.isnan(b["out8"][0, 0, 2][st]).all() and np.isnan(b["tof"][0, 0][st]).all()
+
+
+def test_matcher_aperture_limits(rtus):
+    from oracle import cport
+    rng = np.random.default_rng(5)
+    land = rng.uniform(-0.1, 0.1, (2, 3000))
+    tof = rng.uniform(1e-5, 1e-4, (2, 3000))
+    x_rx = np.linspace(-0.1, 0.1, 4000)                       # the largest aperture the LDS staging takes
+    hit, th, first = rtus.match_elements(land, tof, x_rx, atol=1e-5)
+    for row in range(2):
+        t4 = np.zeros((4, 3000)); t4[0] = tof[row]
+        oh, ot, of = cport.match(land[row], t4, x_rx, 1e-5)
+        assert np.array_equal(hit[row], oh) and np.array_equal(first[row], of) and np.array_equal(th[row], ot)
+    with pytest.raises(rtus.RtusError):
+        rtus.match_elements(land, tof, np.linspace(-0.1, 0.1, 4001))
+    one = rtus.match_elements(land[:, :1], tof[:, :1], x_rx[:1], atol=1.0)    # 1 ray, 1 element
+    assert one[0].shape == (2, 1) and one[0].all()
