@@ -90,6 +90,13 @@ int rtus_device_count(int *count);
  *   RTUS_SHOOT_FAST_MATH  the same laws in vector form (no trigonometry): ~1e-15 relative from the above on
  *                         regular rays, may differ on degenerate ones (exactly vertical / tangent rays). */
 #define RTUS_SHOOT_FAST_MATH 0x1u
+/* Physically-correct variants — these DEPART from the reference on purpose:
+ *   RTUS_TRUE_PIPE_TANGENT  reflect on the tangent of the circle where it actually is; the reference evaluates
+ *                           the tangent as if the pipe were centred at x = 0 (main_rt.py:237-238, 367)
+ *   RTUS_ANALYTIC_LENS      intersect the reflected line with the analytic lens curve instead of the chords of
+ *                           the alpha-grid polyline (main_rt.py:385-390) */
+#define RTUS_TRUE_PIPE_TANGENT 0x2u
+#define RTUS_ANALYTIC_LENS 0x4u
 
 size_t rtus_shoot_workspace_bytes(int n_rays);
 
@@ -104,6 +111,39 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
                const double *x_a, const double *z_a, int n_tx,
                const double *alpha, const double *z_f, int n_rays,
                double *out8, double *tof4, double *tof, double *land_x, uint8_t *status,
+               unsigned flags, int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Pulse-echo travel times by ROOT-FINDING: tx -> lens -> pipe -> lens -> rx with x_land(alpha) = x_rx solved
+ * per (geometry, tx, rx element) — the north-star's replacement for the reference's grid scan
+ * (main_rt.py:479-501: shoot a launch-angle grid, accept the first ray landing within atol of the element).
+ * The ray chain is exactly rtus_shoot's (same flags); the alpha grid only brackets the roots and defines the
+ * lens polyline.  x_land(alpha) is U-shaped: an element usually has two ray paths.
+ *
+ *   alpha [n_rays]  bracketing grid (ascending) = the lens polyline grid        main_rt.py:479, 338
+ *   x_rx  [n_rx]    receive elements on the plane z = z_land                     main_rt.py:469-477
+ *   tt        [n_geom][n_tx][n_rx]      least travel time over the element's roots; NaN if none
+ *   alpha_root[n_geom][n_tx][n_rx]      nullable: launch angle of that path
+ *   tt_all, alpha_all [..][n_rx][RTUS_MAX_ROOTS]  nullable: every root in ascending alpha, NaN padded
+ *   n_roots   [n_geom][n_tx][n_rx] uint8 nullable
+ * Where the reference's scan reports a hit, one of the roots reproduces its tof to the scan's own resolution
+ * (the hit ray lands up to atol + rtol|x| away from the element: <= ~3e-9 s, more at turning points of x_land).
+ * ---------------------------------------------------------------------------------------- */
+#define RTUS_MAX_ROOTS 4
+
+size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx);
+
+int rtus_solve_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,
+                   const double *d_x_a, const double *d_z_a, int n_tx,
+                   const double *d_alpha, int n_rays, const double *d_x_rx, int n_rx, double z_land,
+                   double *d_tt, double *d_alpha_root, double *d_tt_all, double *d_alpha_all,
+                   uint8_t *d_n_roots, void *d_workspace, size_t workspace_bytes, unsigned flags,
+                   void *stream);
+
+int rtus_solve(const rtus_lens *lens, const double *geoms, int n_geom,
+               const double *x_a, const double *z_a, int n_tx,
+               const double *alpha, int n_rays, const double *x_rx, int n_rx, double z_land,
+               double *tt, double *alpha_root, double *tt_all, double *alpha_all, uint8_t *n_roots,
                unsigned flags, int device);
 
 /* ------------------------------------------------------------------------------------------

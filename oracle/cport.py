@@ -44,6 +44,12 @@ def lib():
         L.orc_tt_layers_newton.restype = None
         L.orc_tt_lens.argtypes = [C.POINTER(_Lens), C.c_double, C.c_double, _dp, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_tt_lens.restype = None
+        L.orc_solve.argtypes = [C.POINTER(_Lens), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.c_int,
+                                _dp, C.c_int, C.c_uint, _dp, _dp, _dp]
+        L.orc_solve.restype = None
+        L.orc_trace_alpha.argtypes = [C.POINTER(_Lens), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, _dp, _dp, C.c_int, C.c_uint, _dp]
+        L.orc_trace_alpha.restype = None
         L.orc_lens_point.argtypes = [C.POINTER(_Lens), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lens_point.restype = None
         L.orc_num_threads.restype = C.c_int
@@ -130,6 +136,37 @@ def tt_lens(xe, ze, xf, zf, a_lo, a_hi, lens=REF_LENS):
     L = _lens(**lens)
     lib().orc_tt_lens(C.byref(L), a_lo, a_hi, xe, ze, xe.size, xf, zf, xf.size, tt, al)
     return tt, al
+
+
+TRUE_TANGENT, ANALYTIC_LENS = 0x2, 0x4
+
+
+def solve(x_a, z_a, z_land, alpha, x_rx, r_outer, pipe_offset, flags=0, lens=REF_LENS):
+    """Root-finding pulse-echo times for one geometry / one tx ->
+    (tt_min [n_rx], tt_all [n_rx, 4], alpha_all [n_rx, 4]); roots in ascending alpha, NaN padded."""
+    alpha, x_rx = _f64(alpha), _f64(x_rx)
+    tt = np.empty(x_rx.size, dtype=np.float64)
+    ta = np.empty((x_rx.size, 4), dtype=np.float64)
+    aa = np.empty((x_rx.size, 4), dtype=np.float64)
+    L = _lens(**lens)
+    lib().orc_solve(C.byref(L), r_outer, pipe_offset, float(x_a), float(z_a), float(z_land), alpha, alpha.size,
+                    x_rx, x_rx.size, flags, tt, ta, aa)
+    return tt, ta, aa
+
+
+def trace_alpha(x_a, z_a, z_f, a, alpha_grid, r_outer, pipe_offset, flags=0, lens=REF_LENS):
+    """One ray at an arbitrary launch angle against the polyline of alpha_grid -> out8 [8]."""
+    alpha_grid = _f64(alpha_grid)
+    L = _lens(**lens)
+    xc = np.empty(alpha_grid.size); zc = np.empty(alpha_grid.size)
+    x, z = C.c_double(), C.c_double()
+    for i, al in enumerate(alpha_grid):
+        lib().orc_lens_point(C.byref(L), float(al), C.byref(x), C.byref(z))
+        xc[i], zc[i] = x.value, z.value
+    o = np.empty(8)
+    lib().orc_trace_alpha(C.byref(L), r_outer, pipe_offset, float(x_a), float(z_a), float(z_f), float(a), xc, zc,
+                          alpha_grid.size, flags, o)
+    return o
 
 
 def num_threads():

@@ -81,6 +81,13 @@ def lib():
     L.rtus_tt_lens.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, ip]
     L.rtus_tt_lens_f32_dev.argtypes = L.rtus_tt_lens_dev.argtypes
     L.rtus_tt_lens_f32.argtypes = L.rtus_tt_lens.argtypes
+    L.rtus_solve_workspace_bytes.argtypes = [ip, ip, ip]
+    L.rtus_solve_workspace_bytes.restype = C.c_size_t
+    L.rtus_solve_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, ip, dp, ip, C.c_double, dp, dp, dp, dp, vp, vp, C.c_size_t,
+                                 C.c_uint, vp]
+    L.rtus_solve.argtypes = [LP, dp, ip, dp, dp, ip, dp, ip, dp, ip, C.c_double, dp, dp, dp, dp, vp, C.c_uint, ip]
+    L.rtus_solve_dev.restype = ip
+    L.rtus_solve.restype = ip
     for name in ("rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32"):
         getattr(L, name).restype = ip
     for name in ("rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match", "rtus_ray_hits_dev",
@@ -98,4 +105,5 @@ def check(status, what):
 EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count",
            "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
            "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers",
-           "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32")
+           "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",
+           "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve")

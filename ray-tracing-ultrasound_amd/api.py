@@ -87,11 +87,19 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
-SHOOT_FAST_MATH = 0x1   # RTUS_SHOOT_FAST_MATH
+SHOOT_FAST_MATH = 0x1       # RTUS_SHOOT_FAST_MATH
+TRUE_PIPE_TANGENT = 0x2     # RTUS_TRUE_PIPE_TANGENT  (physically correct; not the reference)
+ANALYTIC_LENS = 0x4         # RTUS_ANALYTIC_LENS      (physically correct; not the reference)
+MAX_ROOTS = 4               # RTUS_MAX_ROOTS
+
+
+def _flags(fast=False, true_tangent=False, analytic_lens=False):
+    return (SHOOT_FAST_MATH if fast else 0) | (TRUE_PIPE_TANGENT if true_tangent else 0) | \
+        (ANALYTIC_LENS if analytic_lens else 0)
 
 
 def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want=("out8",), fast=False,
-                device=0):
+                true_tangent=False, analytic_lens=False, device=0):
     """Forward trace for n_geom geometries x n_tx transmit points in ONE launch.
 
     geoms: [n_geom, 2] of (r_outer, pipe_offset); default = the one geometry in ``params``.
@@ -122,7 +130,7 @@ def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want
     lens = p.lens()
     st = _lib.lib().rtus_shoot(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), _ptr(z_f), N,
                                _ptr(bufs["out8"]), _ptr(bufs["tof4"]), _ptr(bufs["tof"]), _ptr(bufs["land_x"]),
-                               _ptr(bufs["status"]), SHOOT_FAST_MATH if fast else 0, int(device))
+                               _ptr(bufs["status"]), _flags(fast, true_tangent, analytic_lens), int(device))
     _lib.check(st, "rtus_shoot")
     return {w: bufs[w] for w in want}
 
@@ -243,3 +251,35 @@ def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0)
     x_tx, x_rx = _f64(x_tx, "x_tx"), _f64(x_rx, "x_rx")
     return travel_time_layers(z_m, c_m, x_tx, np.full(x_tx.size, float(z_array)), x_rx,
                               np.full(x_rx.size, 2.0 * z_reflector - float(z_array)), device=device)
+
+
+def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params: Params = None, fast=False,
+                       true_tangent=False, analytic_lens=False, all_roots=False, device=0):
+    """Pulse-echo travel times tx -> lens -> pipe -> lens -> rx by root-finding x_land(alpha) = x_rx — the
+    replacement for the reference's grid scan + tolerance matcher (main_rt.py:479-501).
+
+    Returns tt [G, T, E] (least time over the element's ray paths, NaN if none) and the launch angle
+    alpha_root [G, T, E]; with all_roots also (tt_all, alpha_all) [G, T, E, 4] in ascending alpha and
+    n_roots [G, T, E].  ``true_tangent`` / ``analytic_lens`` switch on the physically-correct variants.
+    """
+    p = _resolve(params)
+    x_a, z_a = _f64(x_a, "x_a"), _f64(z_a, "z_a")
+    alpha, x_rx = _f64(alpha, "alpha"), _f64(x_rx, "x_rx")
+    if x_a.shape != z_a.shape:
+        raise ValueError("x_a and z_a must have the same length")
+    if alpha.size < 2:
+        raise ValueError("Curve needs at least two points.")
+    geoms = (np.asarray([[p.r_outer, p.pipe_offset]], dtype=np.float64) if geoms is None
+             else _f64(geoms, "geoms", 2))
+    G, T, E = geoms.shape[0], x_a.size, x_rx.size
+    z_land = p.d if z_land is None else float(z_land)
+    tt = np.empty((G, T, E)); ar = np.empty((G, T, E))
+    ta = np.empty((G, T, E, MAX_ROOTS)) if all_roots else None
+    aa = np.empty((G, T, E, MAX_ROOTS)) if all_roots else None
+    nr = np.empty((G, T, E), dtype=np.uint8) if all_roots else None
+    lens = p.lens()
+    st = _lib.lib().rtus_solve(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), alpha.size,
+                               _ptr(x_rx), E, z_land, _ptr(tt), _ptr(ar), _ptr(ta), _ptr(aa), _ptr(nr),
+                               _flags(fast, true_tangent, analytic_lens), int(device))
+    _lib.check(st, "rtus_solve")
+    return (tt, ar, ta, aa, nr) if all_roots else (tt, ar)

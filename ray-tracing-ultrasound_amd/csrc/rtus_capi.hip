@@ -12,6 +12,11 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
                              void* ws, unsigned flags, hipStream_t s);
+size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx);
+hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
+                             const double* z_a, int n_tx, const double* alpha, int n, const double* x_rx, int n_rx,
+                             double z_land, double* tt, double* alpha_root, double* tt_all,
+                             double* alpha_all, uint8_t* n_roots, void* ws, unsigned flags, hipStream_t s);
 hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batch, int n, const double* x_rx,
                              int n_rx, double atol, double rtol, int32_t* first_ray,
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s);
@@ -122,7 +127,7 @@ static int check_shoot(const rtus_lens* lens, const void* geoms, int n_geom, con
     if (!(lens->c1 > 0) || !(lens->c2 > 0) || lens->c1 == lens->c2) return RTUS_ERR_INVALID_ARG;
     return RTUS_OK;
 }
-#define RTUS_SHOOT_KNOWN_FLAGS (RTUS_SHOOT_FAST_MATH)
+#define RTUS_SHOOT_KNOWN_FLAGS (RTUS_SHOOT_FAST_MATH | RTUS_TRUE_PIPE_TANGENT | RTUS_ANALYTIC_LENS)
 
 int rtus_shoot_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, const double* d_x_a,
                    const double* d_z_a, int n_tx, const double* d_alpha, const double* d_z_f, int n_rays,
@@ -168,6 +173,69 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     if (tof) HIP_TRY(hipMemcpy(tof, tt.p, sizeof(double) * rows * n, hipMemcpyDeviceToHost));
     if (land_x) HIP_TRY(hipMemcpy(land_x, lx.p, sizeof(double) * rows * n, hipMemcpyDeviceToHost));
     if (status) HIP_TRY(hipMemcpy(status, sb.p, rows * n, hipMemcpyDeviceToHost));
+    return RTUS_OK;
+}
+
+// ---------------------------------------------------------------------------- root-finding solve
+size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx)
+{
+    return (n_rays > 0 && n_geom > 0 && n_tx > 0) ? rtus_solve_ws_bytes(n_rays, n_geom, n_tx) : 0;
+}
+
+static int check_solve(const rtus_lens* lens, const void* geoms, int n_geom, const void* x_a, const void* z_a, int n_tx,
+                       const void* alpha, int n_rays, const void* x_rx, int n_rx, double z_land, const void* tt,
+                       unsigned flags)
+{
+    int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, alpha, n_rays);
+    if (st) return st;
+    if (!x_rx || !tt || n_rx <= 0 || !isfinite(z_land)) return RTUS_ERR_INVALID_ARG;
+    if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
+    if ((long long)n_geom * n_tx > 65535) return RTUS_ERR_UNSUPPORTED;
+    return RTUS_OK;
+}
+
+int rtus_solve_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, const double* d_x_a, const double* d_z_a,
+                   int n_tx, const double* d_alpha, int n_rays, const double* d_x_rx, int n_rx, double z_land,
+                   double* d_tt, double* d_alpha_root, double* d_tt_all, double* d_alpha_all, uint8_t* d_n_roots,
+                   void* d_workspace, size_t workspace_bytes, unsigned flags, void* stream)
+{
+    int st = check_solve(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt, flags);
+    if (st) return st;
+    if (!d_workspace || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx)) return RTUS_ERR_WORKSPACE;
+    HIP_TRY(rtus_launch_solve(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt,
+                              d_alpha_root, d_tt_all, d_alpha_all, d_n_roots, d_workspace, flags, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const double* x_a, const double* z_a, int n_tx,
+               const double* alpha, int n_rays, const double* x_rx, int n_rx, double z_land, double* tt,
+               double* alpha_root, double* tt_all, double* alpha_all, uint8_t* n_roots, unsigned flags, int device)
+{
+    int st = check_solve(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, n_rays, x_rx, n_rx, z_land, tt, flags);
+    if (st) return st;
+    if ((st = select_device(device))) return st;
+    const size_t tot = (size_t)n_geom * n_tx * n_rx;
+    DevBuf g, xa, za, al, rx, ws, dt, da, dta, daa, dn;
+    HIP_TRY(g.upload(geoms, sizeof(double) * 2 * n_geom));
+    HIP_TRY(xa.upload(x_a, sizeof(double) * n_tx));
+    HIP_TRY(za.upload(z_a, sizeof(double) * n_tx));
+    HIP_TRY(al.upload(alpha, sizeof(double) * n_rays));
+    HIP_TRY(rx.upload(x_rx, sizeof(double) * n_rx));
+    HIP_TRY(ws.alloc(rtus_solve_ws_bytes(n_rays, n_geom, n_tx)));
+    HIP_TRY(dt.alloc(sizeof(double) * tot));
+    if (alpha_root) HIP_TRY(da.alloc(sizeof(double) * tot));
+    if (tt_all) HIP_TRY(dta.alloc(sizeof(double) * tot * RTUS_MAX_ROOTS));
+    if (alpha_all) HIP_TRY(daa.alloc(sizeof(double) * tot * RTUS_MAX_ROOTS));
+    if (n_roots) HIP_TRY(dn.alloc(tot));
+    HIP_TRY(rtus_launch_solve(*lens, g.as<double>(), n_geom, xa.as<double>(), za.as<double>(), n_tx, al.as<double>(),
+                              n_rays, rx.as<double>(), n_rx, z_land, dt.as<double>(), da.as<double>(), dta.as<double>(),
+                              daa.as<double>(), dn.as<uint8_t>(), ws.p, flags, 0));
+    HIP_TRY(hipStreamSynchronize(0));
+    HIP_TRY(hipMemcpy(tt, dt.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
+    if (alpha_root) HIP_TRY(hipMemcpy(alpha_root, da.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
+    if (tt_all) HIP_TRY(hipMemcpy(tt_all, dta.p, sizeof(double) * tot * RTUS_MAX_ROOTS, hipMemcpyDeviceToHost));
+    if (alpha_all) HIP_TRY(hipMemcpy(alpha_all, daa.p, sizeof(double) * tot * RTUS_MAX_ROOTS, hipMemcpyDeviceToHost));
+    if (n_roots) HIP_TRY(hipMemcpy(n_roots, dn.p, tot, hipMemcpyDeviceToHost));
     return RTUS_OK;
 }
 

@@ -41,6 +41,7 @@ struct ShootArgs {
     double* __restrict__ land_x;        // nullable
     uint8_t* __restrict__ status;       // nullable
     int n, n_tx, n_geom, n0, n1, n2;
+    unsigned flags;
 };
 
 __device__ __forceinline__ double4 make_box(double xmin, double xmax, double zmin, double zmax)
@@ -158,26 +159,24 @@ __device__ __forceinline__ double cap_vertical(double ux, double uz)
     return fabs(ux) < lim ? copysign(lim, ux) : ux;           // NaN stays NaN
 }
 
-// ---- the forward trace -----------------------------------------------------------------------
-template <bool FAST>
-__global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
-{
-    const int n = a.n;
-    const int r_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
-    const bool live = r_raw < n;
-    const int r = live ? r_raw : n - 1;            // tail lanes redo the last ray (no stores): keeps waves full
-    const int tx = blockIdx.y, g = blockIdx.z;
-    const LensK& k = a.k;
+// ---- one ray: lens point P (+ its tangent) -> pipe -> lens -> landing ---------------------------
+// Called by all 64 lanes of a wave together (the crossing search is a lock-step walk).
+struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };
+struct RayOut { double xq, zq, xi, zi, x_in; };
 
-    const double r_outer = a.geoms[2 * g], off = a.geoms[2 * g + 1];   // main_rt.py:466-467
-    const double xa = a.x_a[tx], za = a.z_a[tx];
+template <bool FAST>
+__device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, RayOut& out)
+{
+    const LensK& k = a.k;
+    const int n = a.n;
+    const double2 P = in.P;
+    const double xa = in.xa, za = in.za, r_outer = in.r_outer, off = in.off, zf = in.zf;
 
     // --- element -> lens, refraction lens -> water (main_rt.py:338-349) -----------------------
-    const double2 P = a.curve[r];
     double a_pq, ux = 0.0, uz = 0.0;               // slope of the refracted line; FAST: its unit direction
     double phi_pq = 0.0;
     if (!FAST) {
-        const double phis = a.phi_s[r];
+        const double phis = in.phis;
         const double phi_ap = atan2(za - P.y, xa - P.x);               // :341
         phi_pq = refract_angle(phi_ap, phis, k.c2 / k.c1);             // :345
         a_pq = tan(phi_pq);                                            // :348
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         // Same law without angles.  With t = unit tangent, n = (-tz, tx), v = unit(A - P):
         // sin(theta_1) = sin(phi_ap - phi_n) = -(t.v); theta_2 = asin(eta sin theta_1) (|.|>1 -> NaN = TIR);
         // direction at phi_pq = phi_s - pi/2 + theta_2 is  u = -n cos(theta_2) + t sin(theta_2).
-        const double2 t = a.tan_u[r];
+        const double2 t = in.tu;
         const double vx = xa - P.x, vz = za - P.y;
         const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) / sqrt(vx * vx + vz * vz);
         const double c2 = sqrt(1.0 - s2 * s2);
@@ -207,7 +206,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
     const double xq = upper ? xq1 : xq2, zq = upper ? zq1 : zq2;
 
     // --- reflection on the pipe (main_rt.py:367-376); tangent ignores pipe_offset --
-    const double slope = -xq / sqrt(r_outer * r_outer - xq * xq);      // :237-238
+    // RTUS_TRUE_PIPE_TANGENT (not the reference): tangent of the circle where it actually is
+    const double xt = (a.flags & RTUS_TRUE_PIPE_TANGENT) ? xq - off : xq;
+    const double slope = -xt / sqrt(r_outer * r_outer - xt * xt);      // :237-238
     double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
     if (!FAST) {
         const double phi_sl = atan(slope);                             // :287
@@ -244,9 +245,6 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         const double t0 = fma(m, c0.x, b);
         W.c0pos = __ballot(c0.y > t0); W.c0neg = __ballot(c0.y < t0);   // np.sign(d_0)
     }
-#ifdef RTUS_EXP_NOSCAN   // timing experiment only: pretend every ray crosses at its own index
-    W.found = ~0ull; W.idx = min(r, n - 2);
-#endif
     // Lock-step part: boxes are visited in index order with wave-uniform indices (scalar loads); a ray
     // leaves the walk when a box certifies its answer or when it reaches an 8-point leaf it cannot
     // decide — that leaf it then reads itself (per-lane gather), so the wave never evaluates the
@@ -355,6 +353,20 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         }
     }
 
+    // RTUS_ANALYTIC_LENS (not the reference): slide the chord intersection onto the analytic curve,
+    // Newton on alpha for z(alpha) = m x(alpha) + b from the chord point's polar angle.
+    if (a.flags & RTUS_ANALYTIC_LENS) {                                // wave-uniform flag
+        double al = atan2(xi, zi), lx = xi, lz = zi;
+        for (int it = 0; it < 20; ++it) {
+            double ldz, ldx;
+            lens_eval(k, al, lx, lz, ldz, ldx);
+            const double step = (lz - (m * lx + b)) / (ldz - m * ldx);
+            if (!__any(fabs(step) > 1e-15)) break;
+            al -= (fabs(step) > 1e-15) ? step : 0.0;
+        }
+        xi = isnan(xi) ? xi : lx; zi = isnan(zi) ? zi : lz;
+    }
+
     // --- refraction water -> lens and landing on z = z_f (main_rt.py:396-405) ------------------
     double a3;
     if (!FAST) {
@@ -381,8 +393,33 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
         a3 = w3z / cap_vertical(tz * c2 + tx_ * s2, w3z);
     }
     const double b3 = zi - a3 * xi;                                    // :402
-    const double zf = a.z_f[r];
     const double x_in = (zf - b3) / a3;                                // :404
+
+    out.xq = xq; out.zq = zq; out.xi = xi; out.zi = zi; out.x_in = x_in;
+}
+
+// ---- the forward trace: one ray of the alpha grid per lane --------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
+{
+    const int n = a.n;
+    const int r_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    const bool live = r_raw < n;
+    const int r = live ? r_raw : n - 1;            // tail lanes redo the last ray (no stores): keeps waves full
+    const int tx = blockIdx.y, g = blockIdx.z;
+    const LensK& k = a.k;
+
+    RayIn in;
+    in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];          // main_rt.py:466-467
+    in.xa = a.x_a[tx]; in.za = a.z_a[tx];
+    in.P = a.curve[r];
+    if (FAST) in.tu = a.tan_u[r]; else in.phis = a.phi_s[r];
+    in.zf = a.z_f[r];
+    RayOut o_;
+    trace_ray<FAST>(a, in, o_);
+    const double2 P = in.P;
+    const double xa = in.xa, za = in.za, zf = in.zf;
+    const double xq = o_.xq, zq = o_.zq, xi = o_.xi, zi = o_.zi, x_in = o_.x_in;
 
     if (!live) return;
     const size_t row = (size_t)g * a.n_tx + tx;
@@ -403,6 +440,124 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_shoot_kernel(ShootArgs a)
             t[0] = t1; t[(size_t)n] = t2; t[2 * (size_t)n] = t3; t[3 * (size_t)n] = t4;
         }
         if (a.tof) a.tof[row * n + r] = ((t1 + t2) + t3) + t4;         // main_rt.py:497-500
+    }
+}
+
+// ---- pulse-echo root-finding solve ------------------------------------------------------------
+// The reference matches elements to whichever GRID ray happens to land within a tolerance
+// (main_rt.py:487-501).  Here x_land(alpha) = x_rx is solved: the grid trace (rtus_shoot_kernel)
+// only brackets the roots — consecutive finite grid rays whose landing points straddle the element —
+// and each bracket is refined with the Illinois variant of regula falsi, every evaluation being a
+// full trace_ray at that lane's own alpha.  x_land(alpha) is U-shaped, so an element usually has two
+// ray paths; all (up to RTUS_MAX_ROOTS) are returned in ascending alpha, plus the least-time one.
+// Lanes = consecutive rx elements of one (geometry, tx) row; brackets are found by a lock-step scan of
+// the row's land_x (wave-uniform index -> scalar loads) against each lane's own element.
+struct SolveArgs {
+    ShootArgs s;                        // lens, geometry, tx, polyline + boxes, flags
+    const double* __restrict__ alpha;   // [n]  grid
+    const double* __restrict__ land_x;  // [rows][n] landing x of the grid rays on z = z_land
+    const double* __restrict__ x_rx;    // [n_rx]
+    double z_land;
+    int n_rx;
+    double* __restrict__ tt;            // [rows][n_rx] least-time root (NaN: none)
+    double* __restrict__ alpha_root;    // nullable, its launch angle
+    double* __restrict__ tt_all;        // nullable [rows][n_rx][RTUS_MAX_ROOTS]
+    double* __restrict__ alpha_all;     // nullable [rows][n_rx][RTUS_MAX_ROOTS]
+    uint8_t* __restrict__ n_roots;      // nullable [rows][n_rx]
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
+{
+    const ShootArgs& a = q.s;
+    const LensK& k = a.k;
+    const int n = a.n;
+    const int e_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    const bool live = e_raw < q.n_rx;
+    const int e = live ? e_raw : q.n_rx - 1;
+    const int row = blockIdx.y, g = row / a.n_tx, tx = row - g * a.n_tx;
+    const double xe = q.x_rx[e];
+    const double* __restrict__ lrow = q.land_x + (size_t)row * n;
+
+    // brackets: grid pairs (r, r+1), both finite, f(r) != 0 and f(r+1) on the other side or zero
+    int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
+    double fprev = lrow[0] - xe;
+    for (int r = 1; r < n; ++r) {
+        const double fcur = lrow[r] - xe;                              // wave-uniform index: scalar load
+        const bool st = isfinite(fprev) && isfinite(fcur) && ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
+        if (st) {
+            b0 = cnt == 0 ? r - 1 : b0; b1 = cnt == 1 ? r - 1 : b1;
+            b2 = cnt == 2 ? r - 1 : b2; b3 = cnt == 3 ? r - 1 : b3;
+            ++cnt;
+        }
+        fprev = fcur;
+    }
+    cnt = min(cnt, RTUS_MAX_ROOTS);
+
+    RayIn in;
+    in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];
+    in.xa = a.x_a[tx]; in.za = a.z_a[tx]; in.zf = q.z_land;
+    double tmin = NAN, amin = NAN, tk[RTUS_MAX_ROOTS], ak[RTUS_MAX_ROOTS];
+    int nr = 0;
+#pragma unroll
+    for (int kk = 0; kk < RTUS_MAX_ROOTS; ++kk) {
+        tk[kk] = NAN; ak[kk] = NAN;
+        const int br = kk == 0 ? b0 : (kk == 1 ? b1 : (kk == 2 ? b2 : b3));
+        const bool mine = kk < cnt;
+        if (!__any(mine)) continue;                                    // wave-uniform
+        const int bs = mine ? br : 0;
+        double al = q.alpha[bs], ah = q.alpha[bs + 1];
+        double fl = lrow[bs] - xe, fh = lrow[bs + 1] - xe;
+        double ac = ah, fc = fh;
+        RayOut o;
+        bool ok = mine && fh != 0.0;                                   // fh == 0: the grid ray itself is the root
+        bool dead = false;
+        for (int it = 0; it < 64; ++it) {
+            const bool work = ok && !dead && fabs(fc) > 1e-13 && fabs(ah - al) > 4e-16 * fmax(fabs(al), fabs(ah));
+            if (!__any(work) && it > 0) break;
+            if (work || it == 0) {
+                double cand = (al * fh - ah * fl) / (fh - fl);
+                if (!(cand > fmin(al, ah) && cand < fmax(al, ah))) cand = 0.5 * (al + ah);
+                ac = (work) ? cand : ac;
+            }
+            double px, pz, dz, dx;
+            lens_eval(k, ac, px, pz, dz, dx);                          // main_rt.py:338, 344 at this lane's alpha
+            in.P = make_double2(px, pz);
+            if (FAST) { const double rt = 1.0 / sqrt(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+            else in.phis = atan2(dz, dx);
+            trace_ray<FAST>(a, in, o);                                 // all 64 lanes together
+            fc = o.x_in - xe;
+            if (work) {
+                if (!isfinite(fc)) dead = true;                        // the branch ends inside the bracket
+                else if ((fc < 0.0) == (fh < 0.0)) { ah = ac; fh = fc; fl *= 0.5; }   // Illinois: halve the stale end
+                else { al = ah; fl = fh; ah = ac; fh = fc; }
+            }
+        }
+        const bool root = mine && !dead && fabs(fc) < 1e-9;             // |f| large at convergence: a jump, not a root
+        const double t1 = dist2d(in.xa, in.za, in.P.x, in.P.y) / k.c1;
+        const double t2 = dist2d(in.P.x, in.P.y, o.xq, o.zq) / k.c2;
+        const double t3 = dist2d(o.xq, o.zq, o.xi, o.zi) / k.c2;
+        const double t4 = dist2d(o.xi, o.zi, o.x_in, q.z_land) / k.c1;
+        const double T = ((t1 + t2) + t3) + t4;
+        if (root) {
+            // roots are stored compacted (ascending alpha)
+            tk[0] = nr == 0 ? T : tk[0]; ak[0] = nr == 0 ? ac : ak[0];
+            tk[1] = nr == 1 ? T : tk[1]; ak[1] = nr == 1 ? ac : ak[1];
+            tk[2] = nr == 2 ? T : tk[2]; ak[2] = nr == 2 ? ac : ak[2];
+            tk[3] = nr == 3 ? T : tk[3]; ak[3] = nr == 3 ? ac : ak[3];
+            if (!(tmin <= T)) { tmin = T; amin = ac; }
+            ++nr;
+        }
+    }
+    if (!live) return;
+    const size_t o1 = (size_t)row * q.n_rx + e;
+    q.tt[o1] = tmin;
+    if (q.alpha_root) q.alpha_root[o1] = amin;
+    if (q.n_roots) q.n_roots[o1] = (uint8_t)nr;
+#pragma unroll
+    for (int kk = 0; kk < RTUS_MAX_ROOTS; ++kk) {
+        if (q.tt_all) q.tt_all[o1 * RTUS_MAX_ROOTS + kk] = tk[kk];
+        if (q.alpha_all) q.alpha_all[o1 * RTUS_MAX_ROOTS + kk] = ak[kk];
     }
 }
 
@@ -434,6 +589,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
     a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    a.flags = flags;
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
                        (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
                        (double4*)a.node2);
@@ -452,3 +608,53 @@ extern "C" int rtus_dbg_read(unsigned long long* out, int reset)
     return 0;
 }
 #endif
+
+// Workspace of the solve = shoot workspace + z_f[n] (all z_land) + land_x[rows][n].
+static size_t sws_zf_off(int n) { return align32(rtus_ws_bytes(n)); }
+static size_t sws_land_off(int n) { return align32(sws_zf_off(n) + (size_t)n * sizeof(double)); }
+size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx)
+{
+    return sws_land_off(n) + (size_t)n_geom * n_tx * (size_t)n * sizeof(double);
+}
+
+__global__ void rtus_fill_kernel(double* __restrict__ p, double v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
+                             const double* z_a, int n_tx, const double* alpha, int n, const double* x_rx, int n_rx,
+                             double z_land, double* tt, double* alpha_root, double* tt_all,
+                             double* alpha_all, uint8_t* n_roots, void* ws, unsigned flags, hipStream_t s)
+{
+    char* w = (char*)ws;
+    double* z_f_scratch = (double*)(w + sws_zf_off(n));
+    double* land = (double*)(w + sws_land_off(n));
+    // 1. grid trace with z_f = z_land for every ray
+    hipLaunchKernelGGL(rtus_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z_f_scratch, z_land, n);
+    hipError_t e = rtus_launch_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f_scratch, n, nullptr, nullptr,
+                                     nullptr, land, nullptr, ws, flags, s);
+    if (e != hipSuccess) return e;
+    // 2. bracket + refine
+    SolveArgs q;
+    ShootArgs& a = q.s;
+    a.k = make_lens_k(lens);
+    a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f_scratch;
+    a.curve = (const double2*)w;
+    a.phi_s = (const double*)(w + ws_phis_off(n));
+    a.tan_u = (const double2*)(w + ws_tanu_off(n));
+    a.node0 = (const double4*)(w + ws_node0_off(n));
+    a.node1 = (const double4*)(w + ws_node1_off(n));
+    a.node2 = (const double4*)(w + ws_node2_off(n));
+    a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr;
+    a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
+    a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    a.flags = flags;
+    q.alpha = alpha; q.land_x = land; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
+    q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
+    const dim3 grid((n_rx + RTUS_BLOCK - 1) / RTUS_BLOCK, n_geom * n_tx);
+    if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_solve_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, q);
+    else hipLaunchKernelGGL(rtus_solve_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, q);
+    return hipGetLastError();
+}

@@ -150,3 +150,23 @@ def test_lens_two_point_oracle_is_pinned_by_reference_rays():
     tt, al = cport.tt_lens([0.0], [D_PLANE], o[2][idx], o[3][idx], -am, am)
     assert np.max(np.abs(tt[0] - (t4[0] + t4[1])[idx])) < 1e-16
     assert np.max(np.abs(al[0] - alpha[idx])) < 1e-8
+
+
+def test_oracle_root_find_reproduces_scan_hits():
+    """orc_solve (bisection on x_land(alpha) = x_rx) vs the reference's database_2.csv: each tolerance hit of the
+    grid scan is one of the element's roots, to the scan's own resolution (< 6e-8 s; offset-0 continuum excluded)."""
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "database_2.csv"))))[1:]
+    db_hit = np.array([r[3] == "True" for r in rows]).reshape(210, 65)
+    db_tof = np.array([float(r[4]) for r in rows]).reshape(210, 65)
+    s = load_golden("sweep_cfg.npz")
+    alpha, geoms, xe = s["alpha"], s["geoms"], s["x_elem"]
+    checked = 0
+    for gi in range(0, 210, 5):
+        if not db_hit[gi].any() or abs(geoms[gi, 1]) < 1e-12:
+            continue
+        tt, ta, aa = cport.solve(0.0, D_PLANE, D_PLANE, alpha, xe, geoms[gi, 0], geoms[gi, 1])
+        for e in np.nonzero(db_hit[gi])[0]:
+            assert np.nanmin(np.abs(ta[e] - db_tof[gi, e])) < 6e-8
+            checked += 1
+        assert np.nanmin(tt) >= np.nanmin(ta) - 1e-18
+    assert checked > 80
