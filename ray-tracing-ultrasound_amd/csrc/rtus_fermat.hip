@@ -14,8 +14,9 @@
 //
 // Cost model (measured, scripts/ubench_fp64.hip): an fp64 fma/mul/add wave-op costs ~2 ns of SIMD
 // time, v_rsq_f64 / v_rcp_f64 ~6.8 ns (seed accuracy 5e-8), IEEE sqrt ~36 ns, IEEE divide ~25 ns.
-// So the iteration uses the raw rsq/rcp seeds (Newton does not need an exact Jacobian, and the
-// 5e-8 perturbation of the fixed point is removed below), and no IEEE sqrt/divide anywhere.
+// So the Newton iteration runs entirely on the fp32 pipe (v_fma_f32 ~1 ns, v_rsq_f32 / v_rcp_f32
+// ~3.4 ns): it only has to bring q within 1e-4 of the root — Newton needs neither an exact Jacobian nor
+// an exact residual for that — and the fp64 result is produced afterwards; no IEEE sqrt/divide anywhere.
 //   * a lane stops when the step it would take is |dq| <= 1e-4 q; it does NOT take that step, so the
 //     seeds of its last evaluation belong to its q and are refined (one cubic step, ~1 ulp) instead
 //     of being recomputed;
@@ -25,7 +26,6 @@
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced,
 // the element coordinates and all layer constants are wave-uniform (SGPRs).
 #include "rtus_device.h"
-#include <stdlib.h>
 
 struct LayerArgs {
     double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used, +inf beyond)
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
     const double xe_v = a.xe[el], ze_v = a.ze[el];
 
     double h[NL], hr[NL], kk[NL], hc[NL];
-    double inv_cm = 0.0, rs0 = 0.0, rhm = 0.0, asym = 0.0, ze_prev = NAN;
+    double inv_cm = 0.0, ze_prev = NAN;
+    float hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
     double qs1 = 0.0, qs2 = 0.0, xe1 = 0.0, xe2 = 0.0;    // signed solutions / positions of the two previous elements
     int hist = 0;
     bool valid = false;
@@ -106,8 +107,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 cm = faster ? a.c[i] : cm;
                 inv_cm = faster ? a.inv_c[i] : inv_cm;
             }
-            double s0 = 0.0, hm = 0.0;
-            asym = 0.0;
+            double s0 = 0.0, hm = 0.0, asym = 0.0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
@@ -120,61 +120,70 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 hm += fastest ? h[i] : 0.0;
                 asym += fastest ? 0.0 : hr[i] * __builtin_amdgcn_rsq(kk[i]);
             }
-            // lower-bound reciprocals rounded DOWN a little so that lb stays a lower bound
-            rs0 = __builtin_amdgcn_rcp(s0) * (1.0 - 1e-6);
-            rhm = __builtin_amdgcn_rcp(hm) * (1.0 - 1e-6);
+            // lower-bound reciprocals shaved a little so that lb stays a lower bound under fp32 rounding
+            rs0f = __builtin_amdgcn_rcpf((float)s0) * (1.0f - 4e-6f);
+            rhmf = __builtin_amdgcn_rcpf((float)hm) * (1.0f - 4e-6f);
+            asymf = (float)asym * (1.0f + 4e-6f);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
         }
         const double dxs = xf - xe;
         const double X = fabs(dxs);
-        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym
-        const double lb = valid ? fmax(fmax(X * rs0, (X - asym) * rhm), 0.0) : 0.0;
-        double q = lb;
+        // ---- Newton iteration in fp32 -----------------------------------------------------------
+        // The loop only has to bring q within ~1e-4 of the root (the fp64 expansion below removes the
+        // rest to third order), so it runs on the fp32 pipe: half the issue cost of fp64 and native
+        // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise three orders below
+        // the stopping threshold.
+        const float Xf = (float)X;
+        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
+        const float lb = valid ? fmaxf(fmaxf(Xf * rs0f, (Xf - asymf) * rhmf), 0.0f) : 0.0f;
+        float q = lb;
         if (hist >= 2 && xe1 != xe2) {                      // wave-uniform
-            const double t = (xe - xe1) * rcp_seed(xe1 - xe2);
-            q = fmax(fabs(fma(qs1 - qs2, t, qs1)), lb);     // linear extrapolation of the signed solution
+            const float t = (float)(xe - xe1) * __builtin_amdgcn_rcpf((float)(xe1 - xe2));
+            q = fmaxf(fabsf(fmaf((float)(qs1 - qs2), t, (float)qs1)), lb);   // linear extrapolation of the signed solution
         } else if (hist >= 1) {
-            q = fmax(fabs(qs1) * X * rcp_seed(fmax(fabs(xf - xe1), 1e-30)), lb);   // proportional
+            q = fmaxf(fabsf((float)qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);
         }
-        q = valid ? q : 0.0;
-        double y[NL];
+        q = valid ? q : 0.0f;
+        float y[NL], rS3 = 0.0f;
         int it = 0;
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
-            const double q2 = q * q;
-            double S1 = 0.0, S3 = 0.0;
+            const float q2 = q * q;
+            float S1 = 0.0f, S3 = 0.0f;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                y[i] = rsqrt_seed(fma(kk[i], q2, 1.0));
-                const double hw = hr[i] * y[i];
+                y[i] = __builtin_amdgcn_rsqf(fmaf(kkf[i], q2, 1.0f));
+                const float hw = hrf[i] * y[i];
                 S1 += hw;
-                S3 = fma(hw, y[i] * y[i], S3);
+                S3 = fmaf(hw, y[i] * y[i], S3);
             }
-            const double dq = fma(-S1, q, X) * rcp_seed(S3);
+            rS3 = __builtin_amdgcn_rcpf(S3);
+            const float dq = fmaf(-S1, q, Xf) * rS3;
             // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
             // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
-            const bool small = !(fabs(dq) > 1e-4 * q) || !valid;
+            const bool small = !(fabsf(dq) > 1e-4f * q) || !valid;
             if (__all(small)) break;
-            q = small ? q : fmax(q + dq, lb);
+            q = small ? q : fmaxf(q + dq, lb);
             if (ITERS) it += small ? 0 : 1;
         }
-        // Accurate T at q (not the exact root: |X - X(q)| <~ 1e-4 X) + the Fermat expansion in the
-        // residual dXr = X - X(q):  T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
+        // ---- fp64: accurate T at q + the Fermat expansion in the residual dXr = X - X(q) ----------
+        // T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
         // p = sin(theta)/cm = q u / cm,  dp/dX = u^3 / (cm X'(q)),  u = 1/sqrt(1+q^2).
-        const double q2 = q * q;
+        const double qd = (double)q;
+        const double q2 = qd * qd;
         const double a1 = 1.0 + q2;
-        const double u = rsqrt_refine(a1, rsqrt_seed(a1));
-        double A1 = 0.0, A3 = 0.0, ST = 0.0;
+        const double u = rsqrt_refine(a1, (double)__builtin_amdgcn_rsqf((float)a1));
+        double A1 = 0.0, ST = 0.0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const double w = rsqrt_refine(fma(kk[i], q2, 1.0), y[i]);
-            const double hw = hr[i] * w;
-            A1 += hw;
-            A3 = fma(hw, w * w, A3);
+            const double w = rsqrt_refine(fma(kk[i], q2, 1.0), (double)y[i]);
+            A1 = fma(hr[i], w, A1);
             ST = fma(hc[i], w, ST);
         }
-        const double dXr = fma(-A1, q, X);
+        const double dXr = fma(-A1, qd, X);
         const double uc = u * inv_cm;
-        const double rA3 = rcp_seed(A3);                    // only scales the 2nd-order term / the predictor
-        double T = fma(a1 * u, ST, dXr * fma(0.5 * (u * u) * (uc * rA3), dXr, q * uc));
+        const double rA3 = (double)rS3;                     // 1/X'(q) to 1e-7: only scales the 2nd-order term / the predictor
+        double T = fma(a1 * u, ST, dXr * fma(0.5 * (u * u) * (uc * rA3), dXr, qd * uc));
         if (!valid) T = NAN;
         if (live) {
             const size_t o = (size_t)e * a.n_f + f;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             if (ITERS) a.iters[o] = (uint8_t)it;
         }
         // history for the predictor: the root itself, q + dXr / X'(q), signed by the side of the element
-        const double qroot = fma(dXr, rA3, q);
+        const double qroot = fma(dXr, rA3, qd);
         qs2 = qs1; xe2 = xe1;
         qs1 = dxs < 0.0 ? -qroot : qroot; xe1 = xe;
         ++hist;
@@ -202,7 +211,6 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
     const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
     int eb = (int)(wave_solves / (1024LL * 4));
     eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
-    if (const char* ev = getenv("RTUS_EB")) { int v = atoi(ev); if (v >= 1 && v <= 64) eb = v; }   // tuning override
     a.eb = eb;
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb), block(RTUS_BLOCK);
     switch (n_if + 1) {
