@@ -254,6 +254,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(wl)
     if rank == 0 and world == 1 and not args.no_extra and wl == "cfg2_planar":
         out["extra"] = extra_ref_path(dev_api, rtus, t64, torch)
+        if not args.no_cpu_baseline:
+            out["extra"]["cpu_ref_path"] = cpu_ref_path()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -295,6 +297,28 @@ def cpu_baseline(wl):
                       f"oracle/rt_oracle.c orc_shoot_batch (fp64, O(N) polyline scan per ray, OpenMP)"}
 
 
+def cpu_ref_path():
+    """CPU legs of the reference-parity path on this host: the NumPy port (the reference's own O(N^2) scan as
+    2-D array ops, 1 core) and the C port (OpenMP) — forward trace only, reference sweep geometry."""
+    from oracle import cport, rt_numpy
+    R = ref_inputs("ref_sweep")
+    d = float(R["za"][0])
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 4.0:
+        g = R["geoms"][k % len(R["geoms"])]
+        rt_numpy.shoot(0.0, d, R["zf"], R["alpha"], g[0], g[1])
+        k += 1
+    np_rate = k * R["n"] / (time.perf_counter() - t0)
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 4.0:
+        cport.shoot_batch(R["xa"], R["za"], R["zf"], R["alpha"], R["geoms"])
+        k += 1
+    c_rate = k * R["geoms"].shape[0] * R["n"] / (time.perf_counter() - t0)
+    return {"numpy_port_rays_per_s": round(np_rate, 1), "numpy_port_cores": 1,
+            "c_port_rays_per_s": round(c_rate, 1), "c_port_cores": cport.num_threads(),
+            "note": "forward trace at N = 905 (reference measured in SURVEY: 5.3 k rays/s on one core)"}
+
+
 def extra_ref_path(dev_api, rtus, t64, torch):
     """Side measurement (not the headline): the reference-parity path on the same GPU."""
     res = {}
@@ -318,6 +342,39 @@ def extra_ref_path(dev_api, rtus, t64, torch):
         dt = (time.perf_counter() - t0) / k
         res[kind + ("_fastmath" if fast else "")] = {"Mrays_per_s": round(G * T * N / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4),
                      "rays_per_pass": G * T * N}
+    # curved-lens two-point Fermat solves (BASELINE config 4 geometry: 1024 elements over the reference lens,
+    # 1024 x 256 target strip inside the insonified cone), fp64 and fp32
+    import ctypes as C
+    L = rtus.lib()
+    lens = rtus.Params().lens()
+    d = rtus.Params().d
+    xe = (np.arange(1024) - 511.5) * 0.3e-4
+    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 1024), np.linspace(0.03, 0.07, 256))
+    for name, dt, fn in (("lens_fermat_f64", torch.float64, L.rtus_tt_lens_dev), ("lens_fermat_f32", torch.float32, L.rtus_tt_lens_f32_dev)):
+        mk = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda").to(dt).contiguous()
+        txe, tze, txf, tzf = mk(xe), mk(np.full(1024, d)), mk(xs.ravel()), mk(zs.ravel())
+        out = torch.empty((1024, txf.numel()), dtype=dt, device="cuda")
+        run = lambda: fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, txe.data_ptr(), tze.data_ptr(), 1024,
+                         txf.data_ptr(), tzf.data_ptr(), txf.numel(), out.data_ptr(), None,
+                         torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            assert run() == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / 5
+        n = 1024 * txf.numel()
+        res[name] = {"Mrays_per_s": round(n / dtm / 1e6, 1), "ms_per_pass": round(dtm * 1e3, 3), "solves_per_pass": n}
+    # root-finding pulse-echo solve: the reference sweep's 210 geometries x 65 elements
+    R = ref_inputs("ref_sweep")
+    t0 = time.perf_counter()
+    for _ in range(3):
+        tt, _ = rtus.solve_travel_times(R["xa"], R["za"], R["x_rx"], R["alpha"], R["geoms"], params=rtus.Params())
+    dtm = (time.perf_counter() - t0) / 3
+    res["solve_sweep_host_api"] = {"ms_per_pass": round(dtm * 1e3, 3), "elements": int(tt.size),
+                                   "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe + alloc"}
     return res
 
 

@@ -82,7 +82,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     const int lane = threadIdx.x & 63;
     const int el = min(e0 + lane, k.n_e - 1);
     const R xe_v = k.xe[el], ze_v = k.ze[el];
-    const R tol = sizeof(R) == 4 ? R(2e-6) : R(1e-13);      // |d alpha| at which Newton has converged (rad)
+    const R tol = sizeof(R) == 4 ? R(1e-5) : R(1e-13);      // |d alpha| at which Newton has converged (rad)
+    // ... or when the step can no longer lower T noticeably (T is FLAT in alpha near the lens focus — the lens is
+    // aplanatic — so alpha is ill-conditioned there while T is not): predicted gain g*step/2 below the type's resolution
+    const R tolT = sizeof(R) == 4 ? R(2e-12) : R(1e-21);
 
     R alpha = R(0.5) * (k.a_lo + k.a_hi);
     bool have = false;
@@ -105,13 +108,13 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             R next = alpha + step;
             const bool bad = !(gp > R(0)) || !(next > lo) || !(next < hi);
             if (bad) { next = R(0.5) * (lo + hi); step = next - alpha; }
-            const bool small = !(fabs(step) > tol) || done;
+            const bool small = !(fabs(step) > tol) || !(fabs(g * step) > tolT) || done;
             if (__all(small)) break;
             if (!small) alpha = next; else done = true;     // a finished lane keeps its alpha (T, g belong to it)
         }
         // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g')
         // (only where Newton converged in the interior; a minimum pinned at an interval end keeps T(alpha))
-        const bool interior = gp > R(0) && fabs(g) <= gp * (R(16) * tol);
+        const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
         if (interior) T -= R(0.5) * g * g / gp;
         if (live) {
             const size_t o = (size_t)e * k.n_f + f;
