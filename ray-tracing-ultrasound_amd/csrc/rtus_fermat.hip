@@ -21,7 +21,7 @@
 //     seeds of its last evaluation belong to its q and are refined (one cubic step, ~1 ulp) instead
 //     of being recomputed;
 //   * T at the exact root follows from the Fermat expansion in the residual dXr = X - X(q):
-//     T = T(q) + p dXr + (1/2)(dp/dX) dXr^2,  p = dT/dX = sin(theta)/c  — error O(dXr^3) < 1e-17 s.
+//     T = T(q) + p dXr + (1/2)(dp/dX) dXr^2,  p = dT/dX = sin(theta)/c  — error O(dXr^3) ~ 1e-17 s.
 //
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced,
 // the element coordinates and all layer constants are wave-uniform (SGPRs).
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
     double h[NL], hr[NL], kk[NL], hc[NL];
     double inv_cm = 0.0, ze_prev = NAN;
     float hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
-    double qs1 = 0.0, qs2 = 0.0, xe1 = 0.0, xe2 = 0.0;    // signed solutions / positions of the two previous elements
+    float qs1 = 0.0f, qs2 = 0.0f, d1_old = 0.0f;          // signed solutions of the two previous elements, their slope
+    double xe1 = 0.0, xe2 = 0.0, xe3 = 0.0;              // positions of the three previous elements
     int hist = 0;
     bool valid = false;
     for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
@@ -138,11 +139,18 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
         const float lb = valid ? fmaxf(fmaxf(Xf * rs0f, (Xf - asymf) * rhmf), 0.0f) : 0.0f;
         float q = lb;
+        float d1 = 0.0f;                                    // first divided difference of the signed solution
         if (hist >= 2 && xe1 != xe2) {                      // wave-uniform
-            const float t = (float)(xe - xe1) * __builtin_amdgcn_rcpf((float)(xe1 - xe2));
-            q = fmaxf(fabsf(fmaf((float)(qs1 - qs2), t, (float)qs1)), lb);   // linear extrapolation of the signed solution
+            const float ia = __builtin_amdgcn_rcpf((float)(xe1 - xe2));
+            d1 = (qs1 - qs2) * ia;
+            float pred = fmaf(d1, (float)(xe - xe1), qs1);  // linear extrapolation of the signed solution ...
+            if (hist >= 3 && xe1 != xe3) {                  // ... plus the quadratic term (Newton form)
+                const float dd = (d1 - d1_old) * __builtin_amdgcn_rcpf((float)(xe1 - xe3));
+                pred = fmaf(dd * (float)(xe - xe1), (float)(xe - xe2), pred);
+            }
+            q = fmaxf(fabsf(pred), lb);
         } else if (hist >= 1) {
-            q = fmaxf(fabsf((float)qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);
+            q = fmaxf(fabsf(qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);   // proportional
         }
         q = valid ? q : 0.0f;
         float y[NL], rS3 = 0.0f;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             const float dq = fmaf(-S1, q, Xf) * rS3;
             // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
             // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
-            const bool small = !(fabsf(dq) > 1e-4f * q) || !valid;
+            const bool small = !(fabsf(dq) > 3e-4f * q) || !valid;
             if (__all(small)) break;
             q = small ? q : fmaxf(q + dq, lb);
             if (ITERS) it += small ? 0 : 1;
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         }
         // history for the predictor: the root itself, q + dXr / X'(q), signed by the side of the element
         const double qroot = fma(dXr, rA3, qd);
-        qs2 = qs1; xe2 = xe1;
-        qs1 = dxs < 0.0 ? -qroot : qroot; xe1 = xe;
+        qs2 = qs1; xe3 = xe2; xe2 = xe1; d1_old = d1;
+        qs1 = (float)(dxs < 0.0 ? -qroot : qroot); xe1 = xe;
         ++hist;
     }
 }
