@@ -283,3 +283,11 @@ def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params
                                _flags(fast, true_tangent, analytic_lens), int(device))
     _lib.check(st, "rtus_solve")
     return (tt, ar, ta, aa, nr) if all_roots else (tt, ar)
+
+
+def focal_delays(tt, axis=-2):
+    """Transmit focal law from a travel-time table tt[..., n_elem, n_focal]: the delay each element must be fired
+    with so that all wavefronts reach the focal point together, delays[e, f] = max_e tt[e, f] - tt[e, f]
+    (elements without a ray path — NaN — stay NaN).  SURVEY 8(f) row 4; plain NumPy on the GPU's table."""
+    tt = np.asarray(tt, dtype=np.float64)
+    return np.nanmax(tt, axis=axis, keepdims=True) - tt

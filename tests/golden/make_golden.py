@@ -137,6 +137,31 @@ def main():
     np.savez_compressed(os.path.join(OUT, "edge_cfg.npz"), alpha=alpha, **edge)
     print("edge done")
 
+    # -- 4b. find_line_curve_intersection (main_rt.py:6-168) on hand-made polylines: its corner-case
+    #        semantics (first index wins, sign(0) counts, isclose fallbacks, bounds check) as DATA.
+    cases = {
+        "two_crossings": (0.0, 0.5, [0, 1, 2, 3, 4], [1, 0, 0, 1, 1]),
+        "point_on_line": (0.0, 0.0, [0, 1, 2, 3, 4], [1, 0, -1, -1, -1]),
+        "no_crossing": (0.0, -1.0, [0, 1, 2, 3, 4], [1, 1, 1, 1, 1]),
+        "isclose_point": (0.0, 1.0 - 5e-9, [0, 1, 2, 3, 4], [2, 1, 2, 2, 2]),
+        "collinear": (1.0, 0.0, [0, 1, 2], [1e-12, 1.0, 3.0]),
+        "vertical_segment": (1.0, 0.0, [1, 1, 2], [2, 0, 0]),
+        "steep_line": (250.0, -100.0, [0, 0.2, 0.4, 0.6, 0.8], [0, 1, 3, 2, 0]),
+        "first_of_many": (0.3, 0.1, [0, 1, 2, 3, 4, 5], [1, -1, 1, -1, 1, -1]),
+        "out_of_bounds_y": (1e9, -1e9, [0.5, 1.5, 2.5], [0.0, 1.0, 2.0]),
+    }
+    lc = {}
+    for tag, (m, b, xc, yc) in cases.items():
+        xc, yc = np.asarray(xc, dtype=np.float64), np.asarray(yc, dtype=np.float64)
+        xl = np.linspace(float(xc.min()) - 0.15, float(xc.max()) + 0.15, 64)   # the line as the reference samples it (:385-388)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xi, yi = M.find_line_curve_intersection(xl, m * xl + b, xc, yc)
+        lc[tag + "_in"] = np.concatenate([[m, b], xc, yc])
+        lc[tag + "_out"] = np.asarray([np.nan if xi is None else xi, np.nan if yi is None else yi], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "line_curve_cases.npz"), **lc)
+    print("line_curve cases done")
+
     # -- 5. N-nesting (polyline resolution == ray count, Q3) ------------------------------
     nest = {}
     for n in (181, 1809, 3617):

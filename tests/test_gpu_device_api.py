@@ -1,0 +1,73 @@
+"""GPU: the device-resident API (torch tensors -> *_dev entry points, used by bench.py and multi-GPU runs)
+gives bit-identical results to the host-buffer API, also when replayed from a captured hipGraph."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+from conftest import D_PLANE, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_api_equals_host_api_and_graph_replay(rtus):
+    import torch
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    s = load_golden("sweep_cfg.npz")
+    alpha, geoms, xe = s["alpha"], s["geoms"][::10], s["x_elem"]
+    xa = np.array([0.0, 0.003])
+    za = np.full(2, D_PLANE)
+    zf = np.full(alpha.size, D_PLANE)
+    host = rtus.shoot_batch(xa, za, zf, alpha, geoms, params=rtus.Params(), want=("out8", "tof4", "tof", "land_x", "status"))
+    G, T, N = geoms.shape[0], 2, alpha.size
+    plan = dev_api.ShootPlan(G, T, N, want=("out8", "tof4", "tof", "land_x", "status"), params=rtus.Params())
+    args = [t64(geoms), t64(xa), t64(za), t64(alpha), t64(zf)]
+    out = plan.run(*args)
+    torch.cuda.synchronize()
+    for k, v in host.items():
+        assert np.array_equal(out[k].cpu().numpy(), v, equal_nan=True), k
+    # matcher on device
+    x_rx = t64(xe)
+    first, hit, tof_hit = dev_api.match_dev(out["land_x"].view(G * T, N), out["tof"].view(G * T, N), x_rx, 1e-6, 1e-5)
+    hh, ht, hf = rtus.match_elements(host["land_x"], host["tof"], xe, atol=1e-6)
+    assert np.array_equal(hit.cpu().numpy().astype(bool).reshape(G, T, -1), hh)
+    assert np.array_equal(first.cpu().numpy().reshape(G, T, -1), hf)
+    assert np.array_equal(tof_hit.cpu().numpy().reshape(G, T, -1), ht)
+    # the same launches captured into a hipGraph and replayed
+    for v in out.values():
+        v.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.run(*args)
+            dev_api.match_dev(out["land_x"].view(G * T, N), out["tof"].view(G * T, N), x_rx, 1e-6, 1e-5,
+                              out=(first, hit, tof_hit))
+    torch.cuda.current_stream().wait_stream(side)
+    first.fill_(7)
+    g.replay()
+    torch.cuda.synchronize()
+    for k, v in host.items():
+        assert np.array_equal(out[k].cpu().numpy(), v, equal_nan=True), "graph " + k
+    assert np.array_equal(first.cpu().numpy().reshape(G, T, -1), hf)
+
+
+def test_layers_plan_and_dev_call(rtus):
+    import torch
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    xe = (np.arange(40) - 19.5) * 0.6e-3
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 70), np.linspace(0.025, 0.065, 33))
+    host = rtus.travel_time_layers([0.02], [2330.0, 1483.0], xe, np.zeros(40), xs.ravel(), zs.ravel())
+    a = [t64(xe), t64(np.zeros(40)), t64(xs.ravel()), t64(zs.ravel())]
+    d1 = dev_api.tt_layers_dev([0.02], [2330.0, 1483.0], *a)
+    plan = dev_api.LayersPlan([0.02], [2330.0, 1483.0], *a)
+    d2 = plan.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(d1.cpu().numpy(), host) and np.array_equal(d2.cpu().numpy(), host)
+    with pytest.raises(ValueError):
+        dev_api.tt_layers_dev([0.02], [2330.0, 1483.0], a[0].float(), a[1], a[2], a[3])   # wrong dtype
+    with pytest.raises(ValueError):
+        dev_api.LayersPlan([0.02], [2330.0], *a)                                          # len(c) != len(z_if) + 1

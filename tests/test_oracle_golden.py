@@ -94,34 +94,32 @@ def test_oracle_vs_reference_edges_alltx_nesting():
         _check8(o, n[f"n{k}"], f"n{k}")
 
 
-def test_line_curve_corner_cases():
-    """find_line_curve_intersection semantics (main_rt.py:78-168) on hand-made polylines."""
+def test_line_curve_corner_cases_vs_reference():
+    """find_line_curve_intersection semantics (main_rt.py:78-168): hand-made polylines run through the
+    REFERENCE's own function by tests/golden/make_golden.py (line_curve_cases.npz); the oracle must agree."""
     import ctypes as C
     L = cport.lib()
     L.orc_line_curve.argtypes = [C.c_double, C.c_double, cport._dp, cport._dp, C.c_int,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.orc_line_curve.restype = C.c_int
-
-    def run(m, b, xc, yc):
+    g = load_golden("line_curve_cases.npz")
+    tags = sorted(k[:-3] for k in g.files if k.endswith("_in"))
+    assert len(tags) >= 9
+    for tag in tags:
+        v = g[tag + "_in"]
+        m, b, n = v[0], v[1], (v.size - 2) // 2
+        xc, yc = np.ascontiguousarray(v[2:2 + n]), np.ascontiguousarray(v[2 + n:])
         xi, yi = C.c_double(), C.c_double()
-        ok = L.orc_line_curve(m, b, np.asarray(xc, float), np.asarray(yc, float), len(xc), C.byref(xi), C.byref(yi))
-        return (xi.value, yi.value) if ok else None
-
-    xc = [0.0, 1.0, 2.0, 3.0, 4.0]
-    # two crossings: the earlier INDEX wins (curve dips below the line y=0.5 between 1..3)
-    assert run(0.0, 0.5, xc, [1.0, 0.0, 0.0, 1.0, 1.0]) == (0.5, 0.5)
-    # a curve point exactly on the line counts as a sign change (np.sign(0) = 0) -> segment idx 0
-    assert run(0.0, 0.0, xc, [1.0, 0.0, -1.0, -1.0, -1.0]) == (1.0, 0.0)
-    # no crossing, nothing within isclose -> None
-    assert run(0.0, -1.0, xc, [1.0, 1.0, 1.0, 1.0, 1.0]) is None
-    # no crossing but a point within atol=1e-8 of the line -> that curve point
-    assert run(0.0, 1.0 - 5e-9, xc, [2.0, 1.0, 2.0, 2.0, 2.0]) == (1.0, 1.0)
-    # NaN line -> sign change "found" at 0, then the bounds check fails -> None
-    assert run(float("nan"), 0.0, xc, [1.0, 0.0, -1.0, -1.0, -1.0]) is None
-    # segment parallel to the line within isclose and collinear within isclose -> segment midpoint
-    assert run(1.0, 0.0, [0.0, 1.0, 2.0], [1e-12, 1.0, 3.0]) == (0.5, 0.5)
-    # vertical curve segment (isclose(x1, x2)) uses the line's y at x1 with the +-1e-9 bounds check
-    assert run(1.0, 0.0, [1.0, 1.0, 2.0], [2.0, 0.0, 0.0]) == (1.0, 1.0)
+        ok = L.orc_line_curve(m, b, xc, yc, n, C.byref(xi), C.byref(yi))
+        exp = g[tag + "_out"]
+        if np.isnan(exp[0]):
+            assert not ok, tag                                 # the reference returned (None, None)
+        else:
+            assert ok, tag
+            assert abs(xi.value - exp[0]) < 1e-12 and abs(yi.value - exp[1]) < 1e-9 * max(1.0, abs(exp[1])), tag
+    # NaN line -> sign change "found" at 0, then the bounds check fails -> None (np.sign(NaN) semantics)
+    xi, yi = C.c_double(), C.c_double()
+    assert not L.orc_line_curve(float("nan"), 0.0, np.arange(5.0), np.array([1.0, 0, -1, -1, -1]), 5, C.byref(xi), C.byref(yi))
 
 
 def test_numpy_port_vs_reference():
