@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2_planar",
-                    choices=["cfg2_planar", "cfg3_planar", "ref_sweep", "ref_scale"])
+                    choices=["cfg2_planar", "cfg3_planar", "cfg4_lens_f32", "cfg5_fmc", "ref_sweep", "ref_scale"])
     ap.add_argument("--gather", default="end", choices=["end", "step", "off"],
                     help="--gpus > 1: RCCL all-gather of the row shards once after the K steps (end), "
                          "after every step overlapped with the next kernel (step), or never (off)")
@@ -64,6 +64,31 @@ def planar_inputs(cfg, rank, world):
     xe = x_all[rank * n_e:(rank + 1) * n_e]
     xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, g), np.linspace(zr[0], zr[1], g))
     return dict(z_if=z_if, c=c, xe=xe, ze=np.zeros(n_e), xf=xs.ravel(), zf=zs.ravel(), n_e=n_e, n_f=g * g)
+
+
+def lens_inputs(rank, world):
+    """BASELINE configs[3]: 1024-element array @0.3 mm on z = d over the reference lens h(alpha),
+    water below, 1024 x 1024 target grid inside the insonified cone, fp32; tx rows sharded 1024/world per GPU
+    (this config is a STRONG-scaling shape in BASELINE; here each rank keeps 128 rows = the 8-GPU shard)."""
+    import rtus
+    n_e = 128
+    x_all = (np.arange(n_e * world) - (n_e * world - 1) / 2.0) * 0.3e-4
+    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 1024), np.linspace(0.03, 0.07, 1024))
+    return dict(xe=x_all[rank * n_e:(rank + 1) * n_e], ze=np.full(n_e, rtus.Params().d), xf=xs.ravel(), zf=zs.ravel(),
+                n_e=n_e, n_f=xs.size)
+
+
+def fmc_inputs(rank, world):
+    """BASELINE configs[4]: 2048 tx x 2048 rx on z = 0, 3 horizontal layers, planar reflector at
+    depth — unfolded about the reflector into a 5-layer one-way problem; each rank owns 256 tx rows."""
+    z_if, c, z_r = np.array([0.008, 0.020]), np.array([2330.0, 1483.0, 5900.0]), 0.035
+    z_m = np.concatenate([z_if, (2.0 * z_r - z_if)[::-1]])
+    c_m = np.concatenate([c, c[::-1][1:]])
+    n_e = 256
+    x_tx = (np.arange(n_e * world) - (n_e * world - 1) / 2.0) * 0.3e-3
+    x_rx = (np.arange(2048) - 1023.5) * 0.3e-3
+    return dict(z_if=z_m, c=c_m, xe=x_tx[rank * n_e:(rank + 1) * n_e], ze=np.zeros(n_e), xf=x_rx,
+                zf=np.full(2048, 2.0 * z_r), n_e=n_e, n_f=2048)
 
 
 def ref_inputs(kind):
@@ -114,8 +139,40 @@ def main():
     gather = world > 1 and args.gather == "step"
     gather_end = world > 1 and args.gather == "end"
 
-    if wl in ("cfg2_planar", "cfg3_planar"):
-        W = planar_inputs(wl, rank, world)
+    if wl == "cfg4_lens_f32":
+        import ctypes as C
+        W = lens_inputs(rank, world)
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+        xe, ze, xf, zf = t32(W["xe"]), t32(W["ze"]), t32(W["xf"]), t32(W["zf"])
+        n_e, n_f = W["n_e"], W["n_f"]
+        dist_api = import_module("ray-tracing-ultrasound_amd.dist")
+        slots = 2 if gather else 1
+        m = dist_api.RowShardedMatrix(world * n_e, n_f, dtype=torch.float32, device=dev, slots=slots)
+        lens = rtus.Params().lens()
+        fn = rtus.lib().rtus_tt_lens_f32_dev
+        units_per_step = n_e * n_f
+        alg_bytes = units_per_step * 4 + (2 * n_e + 2 * n_f) * 4
+        kernel = "rtus_tt_lens_kernel<float>"
+
+        def step(s):
+            b = s % slots
+            if gather:
+                m.wait(b)
+            st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, xf.data_ptr(),
+                    zf.data_ptr(), n_f, m.local(b).data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+            assert st == 0
+            if gather:
+                m.gather(b, async_op=True)
+
+        def drain():
+            for b in range(slots):
+                m.wait(b)
+
+        def finish():
+            if gather_end:
+                m.gather(0)
+    elif wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
+        W = fmc_inputs(rank, world) if wl == "cfg5_fmc" else planar_inputs(wl, rank, world)
         xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
         n_e, n_f = W["n_e"], W["n_f"]
         # double-buffered full matrix; each rank's kernel writes straight into its row block
@@ -221,11 +278,15 @@ def main():
         "metric": "Mrays/sec (elem x focal travel-time solves)", "value": round(value, 3), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if wl == "cfg4_lens_f32" else "f64", "data": "synthetic",
         "config": {"workload": {
             "cfg2_planar": "BASELINE configs[1]: 128-element array, 1 planar interface (z=20 mm, c=2330/1483 m/s), "
                            "128x128 focal grid, fp64, per GPU",
             "cfg3_planar": "BASELINE configs[2]: 256-element array, 2 planar interfaces, 512x512 focal grid, fp64, per GPU",
+            "cfg4_lens_f32": "BASELINE configs[3]: curved parametric interface (the reference lens), 128-element block of a "
+                             "1024-element array x 1024x1024 target grid, fp32, per GPU",
+            "cfg5_fmc": "BASELINE configs[4]: FMC tx/rx travel-time table, 3-layer medium + planar reflector, 256 tx rows x "
+                        "2048 rx, per GPU",
             "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
             "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
             "solves_per_step_per_gpu": units_per_step,
@@ -246,8 +307,8 @@ def main():
         "bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 5),
-        "note": "scalar fp64 root-find: 8-16 B of HBM traffic per solve, so the HBM fraction is small by "
-                "construction; the binding resource is fp64 VALU issue (see DESIGN.md, profiles/)",
+        "note": "scalar root-find: 4-16 B of HBM traffic per solve, so the HBM fraction is small by "
+                "construction; the binding resource is VALU issue (see DESIGN.md, profiles/)",
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -281,6 +342,26 @@ def cpu_baseline(wl):
         return {"value": round(v, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                 "sample": f"{reps} x ({ne} elements x {W['n_f']} focal points) of the same workload, "
                           f"oracle/rt_oracle.c orc_tt_layers_newton (fp64 Newton, OpenMP)"}
+    if wl == "cfg5_fmc":
+        W = fmc_inputs(0, 1)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:64], W["ze"][:64], W["xf"], W["zf"])
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(reps * 64 * W["n_f"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x (64 tx x 2048 rx) of the same table, orc_tt_layers_newton (fp64, OpenMP)"}
+    if wl == "cfg4_lens_f32":
+        W = lens_inputs(0, 1)
+        import rtus
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            cport.tt_lens(W["xe"][:8], W["ze"][:8], W["xf"][:65536], W["zf"][:65536], -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(reps * 8 * 65536 / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x (8 elements x 65536 targets), orc_tt_lens (golden-section search in long double — a "
+                          "checker, not a tuned CPU solver; OpenMP)"}
     R = ref_inputs(wl)
     g = R["geoms"][:: max(1, R["geoms"].shape[0] // 16)][:16]
     xa = R["xa"][:8]

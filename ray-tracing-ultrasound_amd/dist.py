@@ -60,6 +60,17 @@ class RowShardedMatrix:
         return self.full[slot][:self.n_rows]
 
 
+def sharded_rows(n_rows, n_cols, row_solver, *, dtype=torch.float64, device="cuda", group=None):
+    """Generic row-sharded table: ``row_solver(lo, hi, out)`` fills rows [lo, hi) of the table into ``out``
+    ([hi-lo, n_cols] view of this rank's block); the blocks are then all-gathered in place on every rank."""
+    m = RowShardedMatrix(n_rows, n_cols, dtype=dtype, device=device, slots=1, group=group)
+    n_own = m.hi - m.lo
+    if n_own > 0:
+        row_solver(m.lo, m.hi, m.local(0)[:n_own])
+    m.gather(0)
+    return m.matrix(0)
+
+
 def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=None):
     """Element x focal travel-time matrix computed by row shards on all ranks, gathered everywhere.
 
@@ -69,10 +80,28 @@ def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=No
     """
     if solver is None:
         from .device import tt_layers_dev as solver
-    m = RowShardedMatrix(xe.numel(), xf.numel(), dtype=xe.dtype, device=xe.device, slots=1, group=group)
-    n_own = m.hi - m.lo
-    if n_own > 0:
-        solver(z_if, c, xe[m.lo:m.hi].contiguous(), ze[m.lo:m.hi].contiguous(), xf, zf,
-               out=m.local(0)[:n_own])
-    m.gather(0)
-    return m.matrix(0)
+
+    def rows(lo, hi, out):
+        solver(z_if, c, xe[lo:hi].contiguous(), ze[lo:hi].contiguous(), xf, zf, out=out)
+    return sharded_rows(xe.numel(), xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group)
+
+
+def travel_time_lens_sharded(xe, ze, xf, zf, *, params=None, alpha_lo=None, alpha_hi=None, group=None):
+    """BASELINE config 4 across ranks: curved-lens Fermat table (fp64 or fp32 by the tensors' dtype), tx rows
+    sharded, reassembled by the all-gather."""
+    import ctypes as C
+    from . import _lib
+    from .api import ALPHA_MAX, _resolve
+    p = _resolve(params)
+    lens = p.lens()
+    fn = _lib.lib().rtus_tt_lens_dev if xe.dtype == torch.float64 else _lib.lib().rtus_tt_lens_f32_dev
+    a_lo = -ALPHA_MAX if alpha_lo is None else float(alpha_lo)
+    a_hi = ALPHA_MAX if alpha_hi is None else float(alpha_hi)
+
+    def rows(lo, hi, out):
+        xs, zs = xe[lo:hi].contiguous(), ze[lo:hi].contiguous()
+        st = fn(C.byref(lens), a_lo, a_hi, xs.data_ptr(), zs.data_ptr(), hi - lo, xf.data_ptr(), zf.data_ptr(),
+                xf.numel(), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rtus_tt_lens_dev")
+        torch.cuda.current_stream().synchronize()          # xs / zs must outlive the launch
+    return sharded_rows(xe.numel(), xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group)
