@@ -135,19 +135,20 @@ def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want
     return {w: bufs[w] for w in want}
 
 
-def shoot_rays(x_a, z_a, z_f, alpha, plot=False, *, params: Params = None, device=0):
+def shoot_rays(x_a, z_a, z_f, alpha, plot=False, *, params: Params = None, device=0, **options):
     """Drop-in for the reference's shoot_rays (main_rt.py:337): one transmit point, one geometry.
 
     Returns the same dict of eight float64[N] arrays (main_rt.py:432-441); invalid rays are NaN.
     ``plot`` is accepted for signature compatibility; plotting (main_rt.py:407-430) is out of scope
-    and the default is False so the call never blocks on a GUI.
+    and the default is False so the call never blocks on a GUI.  ``options``: fast / true_tangent /
+    analytic_lens as in :func:`shoot_batch` (all off = the reference's arithmetic).
     """
     if plot:
         warnings.warn("rtus.shoot_rays: plotting is not part of the accelerated path; ignoring plot=True",
                       stacklevel=2)
     if np.ndim(x_a) != 0 or np.ndim(z_a) != 0:
         raise ValueError("x_a and z_a are scalars (one transmit point), as in main_rt.py:482")
-    out8 = shoot_batch([x_a], [z_a], z_f, alpha, params=params, device=device)["out8"][0, 0]
+    out8 = shoot_batch([x_a], [z_a], z_f, alpha, params=params, device=device, **options)["out8"][0, 0]
     return {k: out8[i].copy() for i, k in enumerate(KEYS)}
 
 

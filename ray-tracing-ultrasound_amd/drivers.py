@@ -72,3 +72,37 @@ def rows_to_csv(rows, header=None) -> str:
         w.writerow(header)
     w.writerows(rows)
     return buf.getvalue()
+
+
+def compare_against_database(database_csv, *, params=None, backend=None, **kw):
+    """The tail of main_compare.py (:485-500, 526-553) without pandas: pick the (offset, radius) group of
+    ``database_csv`` nearest to this configuration, sum the four segment times per ray (NaN if any is NaN),
+    subtract this run's sums ray by ray and return (individual_errors, num_hitted, mse) with
+    mse = sum(err^2 over non-NaN) / num_hitted, exactly as the reference prints them.
+
+    ``database.csv`` is NOT in the reference checkout (.MISSING_LARGE_BLOBS): a missing file raises
+    FileNotFoundError with that explanation instead of the reference's bare pandas error.
+    """
+    import os
+    if database_csv is None or not os.path.exists(database_csv):
+        raise FileNotFoundError(f"{database_csv!r} not found — the reference's database.csv is absent from its checkout "
+                                "(.MISSING_LARGE_BLOBS); pass a CSV with columns alpha,offset,radius,hitted,tof_1..tof_4")
+    p = params or api.Params(r_outer=0.037, pipe_offset=0.0038)
+    with open(database_csv, newline="") as fh:
+        rd = csv.DictReader(fh)
+        db = [(float(r["offset"]), float(r["radius"]), [float(r[f"tof_{k}"]) for k in (1, 2, 3, 4)]) for r in rd]
+    off = np.array([d[0] for d in db]); rad = np.array([d[1] for d in db])
+    off_c = off[np.argmin(np.abs(off - p.pipe_offset))]                    # :489-493
+    rad_c = rad[np.argmin(np.abs(rad - p.r_outer))]
+    sel = (off == off_c) & (rad == rad_c)                                  # :495-500
+    t_db = np.array([d[2] for d, s_ in zip(db, sel) if s_], dtype=np.float64)
+    header, rows = compare_rows(params=p, backend=backend, **kw)
+    t_cmp = np.array([r[4:8] for r in rows], dtype=np.float64)
+    if t_db.shape != t_cmp.shape:
+        raise ValueError(f"database group has {t_db.shape[0]} rays, this run {t_cmp.shape[0]} (main_compare.py:544 "
+                         "subtracts them element-wise)")
+    sums_db, sums_cmp = t_db.sum(axis=1), t_cmp.sum(axis=1)                # NaN if any segment is NaN (:526-534)
+    err = sums_db - sums_cmp                                               # :544
+    num_hitted = int(sum(bool(r[3]) for r in rows))                        # :540
+    mse = float(np.sum(np.square(err[~np.isnan(err)])) / num_hitted) if num_hitted else float("nan")   # :550-551
+    return err, num_hitted, mse

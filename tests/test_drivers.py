@@ -74,6 +74,18 @@ def test_drivers_with_oracle_backend():
     _check_compare(drv.rows_to_csv(rows, header))
 
 
+def test_compare_against_database_semantics():
+    """main_compare.py:526-553 with the reference's compare.csv standing in for the absent database.csv:
+    same configuration -> errors at rounding level, num_hitted = 393, mse ~ 0."""
+    drv = import_module("ray-tracing-ultrasound_amd.drivers")
+    err, num_hitted, mse = drv.compare_against_database(os.path.join(GOLDEN, "compare.csv"), backend=OracleBackend)
+    assert err.shape == (1810,) and num_hitted == 393
+    assert np.isnan(err).sum() == 385                     # rows 0-306 and 1732-1809 have a NaN segment
+    assert np.nanmax(np.abs(err)) < 1e-15 and mse < 1e-30
+    with pytest.raises(FileNotFoundError):
+        drv.compare_against_database(os.path.join(GOLDEN, "database.csv"), backend=OracleBackend)
+
+
 @pytest.mark.gpu
 def test_drivers_on_gpu():
     drv = import_module("ray-tracing-ultrasound_amd.drivers")
