@@ -62,6 +62,7 @@ static int check_lens(const rtus_lens* lens, double a_lo, double a_hi, const voi
                       const void* xf, const void* zf, int n_f, const void* tt)
 {
     if (!lens || !xe || !ze || !xf || !zf || !tt || n_e <= 0 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
+    if (n_e > 65535 * 64) return RTUS_ERR_UNSUPPORTED;
     if (!(a_hi > a_lo) || !isfinite(a_lo) || !isfinite(a_hi)) return RTUS_ERR_INVALID_ARG;
     if (!(lens->c1 > 0) || !(lens->c2 > 0) || lens->c1 == lens->c2) return RTUS_ERR_INVALID_ARG;
     return RTUS_OK;
@@ -190,7 +191,7 @@ static int check_solve(const rtus_lens* lens, const void* geoms, int n_geom, con
     if (st) return st;
     if (!x_rx || !tt || n_rx <= 0 || !isfinite(z_land)) return RTUS_ERR_INVALID_ARG;
     if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
-    if ((long long)n_geom * n_tx > 65535) return RTUS_ERR_UNSUPPORTED;
+    if ((long long)n_geom * n_tx > 0x7fffffffLL / (n_rx > 0 ? n_rx : 1)) return RTUS_ERR_UNSUPPORTED;
     return RTUS_OK;
 }
 
@@ -245,7 +246,7 @@ static int check_match(const void* land_x, int n_batch, int n_rays, const void* 
 {
     if (!land_x || !x_rx || n_batch <= 0 || n_rays <= 0 || n_rx <= 0) return RTUS_ERR_INVALID_ARG;
     if (!(atol >= 0) || !(rtol >= 0)) return RTUS_ERR_INVALID_ARG;
-    if (n_batch > 65535 || n_rx > 4000) return RTUS_ERR_UNSUPPORTED;   // x_rx + tolerances live in < 64 KiB of LDS
+    if (n_rx > 4000) return RTUS_ERR_UNSUPPORTED;   // x_rx + tolerances live in < 64 KiB of LDS
     return RTUS_OK;
 }
 
@@ -322,7 +323,7 @@ static int check_layers(const double* z_if, const double* c, int n_if, const voi
     if (!c || (n_if > 0 && !z_if) || !xe || !ze || !xf || !zf || !tt) return RTUS_ERR_INVALID_ARG;
     if (n_if < 0 || n_e <= 0 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
     if (n_if > RTUS_MAX_LAYERS) return RTUS_ERR_UNSUPPORTED;
-    if (n_e > 65535) return RTUS_ERR_UNSUPPORTED;
+    if (n_e > 65535 * 64) return RTUS_ERR_UNSUPPORTED;
     for (int i = 0; i <= n_if; ++i) if (!(c[i] > 0) || !isfinite(c[i])) return RTUS_ERR_INVALID_ARG;
     for (int i = 0; i < n_if; ++i) {
         if (!isfinite(z_if[i])) return RTUS_ERR_INVALID_ARG;

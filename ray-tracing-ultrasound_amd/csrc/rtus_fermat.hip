@@ -220,6 +220,7 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
     const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
     int eb = (int)(wave_solves / (1024LL * 4));
     eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
+    while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one lane per element)
     a.eb = eb;
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb), block(RTUS_BLOCK);
     switch (n_if + 1) {

@@ -16,6 +16,7 @@ struct MatchArgs {
     uint8_t* __restrict__ ray_hit;      // [n_batch][n]      nullable for match
     double atol, rtol;
     int n, n_rx, n_batch;
+    int row0;                           // first batch row of this launch (grid.y is limited to 65535 rows)
 };
 
 // Workgroup = 256 rays of one batch row.  LDS: x_rx[n_rx] then tol[n_rx] (dynamic).
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
     const double win = a.atol + a.rtol * amax;
 
     const int r = blockIdx.x * RTUS_BLOCK + threadIdx.x;
-    const int row = blockIdx.y;
+    const int row = a.row0 + blockIdx.y;
     if (r >= a.n) return;
     const double x = a.land_x[(size_t)row * a.n + r];
     bool any = false;
@@ -99,8 +100,11 @@ hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batc
         hipError_t e = hipMemsetAsync(first_ray, 0x7f, (size_t)n_batch * n_rx * sizeof(int32_t), s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(rtus_match_kernel, dim3((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_batch), dim3(RTUS_BLOCK),
-                       lds, s, a);
+    for (int row0 = 0; row0 < n_batch; row0 += 65535) {
+        a.row0 = row0;
+        hipLaunchKernelGGL(rtus_match_kernel, dim3((n + RTUS_BLOCK - 1) / RTUS_BLOCK, min(65535, n_batch - row0)),
+                           dim3(RTUS_BLOCK), lds, s, a);
+    }
     if (first_ray) {
         const size_t tot = (size_t)n_batch * n_rx;
         hipLaunchKernelGGL(rtus_match_finalize_kernel, dim3((unsigned)((tot + RTUS_BLOCK - 1) / RTUS_BLOCK)),

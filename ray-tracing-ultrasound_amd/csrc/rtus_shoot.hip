@@ -485,6 +485,7 @@ struct SolveArgs {
     double* __restrict__ tt_all;        // nullable [rows][n_rx][RTUS_MAX_ROOTS]
     double* __restrict__ alpha_all;     // nullable [rows][n_rx][RTUS_MAX_ROOTS]
     uint8_t* __restrict__ n_roots;      // nullable [rows][n_rx]
+    int row0;                           // first (geometry, tx) row of this launch (grid.y <= 65535)
 };
 
 template <bool FAST>
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
     const int e_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = e_raw < q.n_rx;
     const int e = live ? e_raw : q.n_rx - 1;
-    const int row = blockIdx.y, g = row / a.n_tx, tx = row - g * a.n_tx;
+    const int row = q.row0 + blockIdx.y, g = row / a.n_tx, tx = row - g * a.n_tx;
     const double xe = q.x_rx[e];
     const double* __restrict__ lrow = q.land_x + (size_t)row * n;
 
@@ -680,8 +681,12 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     a.flags = flags;
     q.alpha = alpha; q.land_x = land; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
-    const dim3 grid((n_rx + RTUS_BLOCK - 1) / RTUS_BLOCK, n_geom * n_tx);
-    if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_solve_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, q);
-    else hipLaunchKernelGGL(rtus_solve_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, q);
+    const long long rows = (long long)n_geom * n_tx;
+    for (long long row0 = 0; row0 < rows; row0 += 65535) {
+        q.row0 = (int)row0;
+        const dim3 grid((n_rx + RTUS_BLOCK - 1) / RTUS_BLOCK, (unsigned)((rows - row0) < 65535 ? (rows - row0) : 65535));
+        if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_solve_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, q);
+        else hipLaunchKernelGGL(rtus_solve_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, q);
+    }
     return hipGetLastError();
 }

@@ -67,3 +67,20 @@ def test_matcher_aperture_limits(rtus):
         rtus.match_elements(land, tof, np.linspace(-0.1, 0.1, 4001))
     one = rtus.match_elements(land[:, :1], tof[:, :1], x_rx[:1], atol=1.0)    # 1 ray, 1 element
     assert one[0].shape == (2, 1) and one[0].all()
+
+
+def test_more_batch_rows_than_one_grid_dimension(rtus):
+    """> 65,535 (geometry, tx) rows: the matcher launches in row chunks; result identical to per-row calls."""
+    from oracle import cport
+    rng = np.random.default_rng(9)
+    rows, n, e = 70001, 48, 7
+    x_rx = np.sort(rng.uniform(-0.01, 0.01, e))
+    land = rng.uniform(-0.012, 0.012, (rows, n))
+    land[:, ::5] = x_rx[rng.integers(0, e, (rows, land[:, ::5].shape[1]))] + 4e-7
+    tof = rng.uniform(1e-5, 1e-4, (rows, n))
+    hit, th, first = rtus.match_elements(land, tof, x_rx, atol=1e-6)
+    for row in (0, 1, 65534, 65535, 65536, 70000):
+        t4 = np.zeros((4, n)); t4[0] = tof[row]
+        oh, ot, of = cport.match(land[row], t4, x_rx, 1e-6)
+        assert np.array_equal(hit[row], oh) and np.array_equal(first[row], of) and np.array_equal(th[row], ot)
+    assert hit.any(axis=1).mean() > 0.9
