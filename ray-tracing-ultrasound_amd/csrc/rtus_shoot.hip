@@ -504,15 +504,23 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
     // brackets: grid pairs (r, r+1), both finite, f(r) != 0 and f(r+1) on the other side or zero
     int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
     double fprev = lrow[0] - xe;
-    for (int r = 1; r < n; ++r) {
-        const double fcur = lrow[r] - xe;                              // wave-uniform index: scalar load
-        const bool st = isfinite(fprev) && isfinite(fcur) && ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
-        if (st) {
-            b0 = cnt == 0 ? r - 1 : b0; b1 = cnt == 1 ? r - 1 : b1;
-            b2 = cnt == 2 ? r - 1 : b2; b3 = cnt == 3 ? r - 1 : b3;
-            ++cnt;
+    for (int r0 = 1; r0 < n; r0 += 8) {                                // 8 grid rays per trip: one batch of scalar loads
+        double lx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lx[i] = lrow[min(r0 + i, n - 1)];  // wave-uniform indices
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + i;
+            const double fcur = lx[i] - xe;
+            const bool st = r < n && isfinite(fprev) && isfinite(fcur) &&
+                            ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
+            if (st) {
+                b0 = cnt == 0 ? r - 1 : b0; b1 = cnt == 1 ? r - 1 : b1;
+                b2 = cnt == 2 ? r - 1 : b2; b3 = cnt == 3 ? r - 1 : b3;
+                ++cnt;
+            }
+            fprev = r < n ? fcur : fprev;
         }
-        fprev = fcur;
     }
     cnt = min(cnt, RTUS_MAX_ROOTS);
 
