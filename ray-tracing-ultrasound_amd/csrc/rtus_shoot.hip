@@ -477,6 +477,8 @@ struct SolveArgs {
     ShootArgs s;                        // lens, geometry, tx, polyline + boxes, flags
     const double* __restrict__ alpha;   // [n]  grid
     const double* __restrict__ land_x;  // [rows][n] landing x of the grid rays on z = z_land
+    const double2* __restrict__ land_box;  // [rows][nb] (min, max) of the finite landing x of rays 64B .. 64B+64
+    int nb;
     const double* __restrict__ x_rx;    // [n_rx]
     double z_land;
     int n_rx;
@@ -503,23 +505,35 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
 
     // brackets: grid pairs (r, r+1), both finite, f(r) != 0 and f(r+1) on the other side or zero
     int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
-    double fprev = lrow[0] - xe;
-    for (int r0 = 1; r0 < n; r0 += 8) {                                // 8 grid rays per trip: one batch of scalar loads
-        double lx[8];
+    // the wave's elements span [xe_lo, xe_hi]; a 64-pair block of grid rays whose landing points all lie
+    // outside that span cannot bracket any of them and is skipped (wave-uniform decision, scalar loads)
+    double xe_lo = xe, xe_hi = xe;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lx[i] = lrow[min(r0 + i, n - 1)];  // wave-uniform indices
+    for (int o = 32; o > 0; o >>= 1) { xe_lo = fmin(xe_lo, __shfl_xor(xe_lo, o)); xe_hi = fmax(xe_hi, __shfl_xor(xe_hi, o)); }
+    const double2* __restrict__ brow = q.land_box + (size_t)row * q.nb;
+    for (int B = 0; B < q.nb; ++B) {
+        const double2 bx = brow[B];
+        if (bx.x > xe_hi || bx.y < xe_lo || !(bx.x <= bx.y)) continue;
+        const int rb = B * 64;
+        double fprev = lrow[rb] - xe;
+        for (int r0 = rb + 1; r0 <= min(rb + 64, n - 1); r0 += 8) {      // 8 grid rays per trip: one batch of scalar loads
+            double lx[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = r0 + i;
-            const double fcur = lx[i] - xe;
-            const bool st = r < n && isfinite(fprev) && isfinite(fcur) &&
-                            ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
-            if (st) {
-                b0 = cnt == 0 ? r - 1 : b0; b1 = cnt == 1 ? r - 1 : b1;
-                b2 = cnt == 2 ? r - 1 : b2; b3 = cnt == 3 ? r - 1 : b3;
-                ++cnt;
+            for (int i = 0; i < 8; ++i) lx[i] = lrow[min(r0 + i, n - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + i;
+                const double fcur = lx[i] - xe;
+                const bool in = r < n && r <= rb + 64;
+                const bool st = in && isfinite(fprev) && isfinite(fcur) &&
+                                ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
+                if (st) {
+                    b0 = cnt == 0 ? r - 1 : b0; b1 = cnt == 1 ? r - 1 : b1;
+                    b2 = cnt == 2 ? r - 1 : b2; b3 = cnt == 3 ? r - 1 : b3;
+                    ++cnt;
+                }
+                fprev = in ? fcur : fprev;
             }
-            fprev = r < n ? fcur : fprev;
         }
     }
     cnt = min(cnt, RTUS_MAX_ROOTS);
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
         bool ok = mine && fh != 0.0;                                   // fh == 0: the grid ray itself is the root
         bool dead = false;
         for (int it = 0; it < 64; ++it) {
-            const bool work = ok && !dead && fabs(fc) > 1e-13 && fabs(ah - al) > 4e-16 * fmax(fabs(al), fabs(ah));
+            const bool work = ok && !dead && fabs(fc) > 1e-13 && fabs(ah - al) > 1e-13;   // |f| < 0.1 pm or bracket < 1e-13 rad (dT/dalpha ~ 1e-5 s/rad)
             if (!__any(work) && it > 0) break;
             if (work || it == 0) {
                 double cand = (al * fh - ah * fl) / (fh - fl);
@@ -643,12 +657,31 @@ extern "C" int rtus_dbg_read(unsigned long long* out, int reset)
 }
 #endif
 
-// Workspace of the solve = shoot workspace + z_f[n] (all z_land) + land_x[rows][n].
+// (min, max) of the finite landing x over the 65 grid rays 64B .. 64B+64 of one row: one wave per block.
+__global__ __launch_bounds__(64) void rtus_land_box_kernel(const double* __restrict__ land, int n, int nb,
+                                                          long long n_boxes, double2* __restrict__ box)
+{
+    const long long id = blockIdx.x;
+    if (id >= n_boxes) return;
+    const long long row = id / nb;
+    const int B = (int)(id - row * nb), l = threadIdx.x;
+    const double* __restrict__ lr = land + row * (long long)n;
+    const int r0 = B * 64 + l;
+    const double v0 = r0 < n ? lr[r0] : NAN, v1 = (l == 63 && r0 + 1 < n) ? lr[r0 + 1] : NAN;
+    double lo = fmin(isfinite(v0) ? v0 : INFINITY, isfinite(v1) ? v1 : INFINITY);
+    double hi = fmax(isfinite(v0) ? v0 : -INFINITY, isfinite(v1) ? v1 : -INFINITY);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+    if (l == 0) box[id] = make_double2(lo, hi);
+}
+
+// Workspace of the solve = shoot workspace + z_f[n] (all z_land) + land_x[rows][n] + land boxes[rows][nb].
 static size_t sws_zf_off(int n) { return align32(rtus_ws_bytes(n)); }
 static size_t sws_land_off(int n) { return align32(sws_zf_off(n) + (size_t)n * sizeof(double)); }
+static size_t sws_box_off(int n, int n_geom, int n_tx) { return align32(sws_land_off(n) + (size_t)n_geom * n_tx * (size_t)n * sizeof(double)); }
 size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx)
 {
-    return sws_land_off(n) + (size_t)n_geom * n_tx * (size_t)n * sizeof(double);
+    return sws_box_off(n, n_geom, n_tx) + (size_t)n_geom * n_tx * (size_t)((n + 63) / 64) * sizeof(double2);
 }
 
 __global__ void rtus_fill_kernel(double* __restrict__ p, double v, int n)
@@ -670,7 +703,12 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     hipError_t e = rtus_launch_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f_scratch, n, nullptr, nullptr,
                                      nullptr, land, nullptr, ws, flags, s);
     if (e != hipSuccess) return e;
-    // 2. bracket + refine
+    // 2. per-row bounding intervals of the landing points, 64 ray pairs each
+    const long long rows_ll = (long long)n_geom * n_tx;
+    const int nb = (n + 63) / 64;
+    double2* boxes = (double2*)(w + sws_box_off(n, n_geom, n_tx));
+    hipLaunchKernelGGL(rtus_land_box_kernel, dim3((unsigned)(rows_ll * nb)), dim3(64), 0, s, land, n, nb, rows_ll * nb, boxes);
+    // 3. bracket + refine
     SolveArgs q;
     ShootArgs& a = q.s;
     a.k = make_lens_k(lens);
@@ -687,7 +725,7 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
     a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
     a.flags = flags;
-    q.alpha = alpha; q.land_x = land; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
+    q.alpha = alpha; q.land_x = land; q.land_box = boxes; q.nb = nb; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
     const long long rows = (long long)n_geom * n_tx;
     for (long long row0 = 0; row0 < rows; row0 += 65535) {
