@@ -48,14 +48,22 @@ struct DevBuf {
     template <class T> T* as() { return (T*)p; }
 };
 
-static int select_device(int device)
+// The host twins run on `device` and put the caller's current device back when they return.
+struct DeviceGuard {
+    int prev = -1;
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+static int select_device_impl(int device, DeviceGuard& g)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return RTUS_ERR_NO_DEVICE;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != device) g.prev = cur;
     HIP_TRY(hipSetDevice(device));
     return RTUS_OK;
 }
+#define select_device(dev) select_device_impl((dev), device_guard_)
 
 // curved-lens helpers (C++ linkage: templates)
 static int check_lens(const rtus_lens* lens, double a_lo, double a_hi, const void* xe, const void* ze, int n_e,
@@ -74,6 +82,7 @@ static int lens_host(const rtus_lens* lens, double a_lo, double a_hi, const R* x
 {
     int st = check_lens(lens, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt);
     if (st) return st;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_e * n_f;
     DevBuf dxe, dze, dxf, dzf, dtt, dal;
@@ -151,6 +160,7 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f, n_rays);
     if (st) return st;
     if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t rows = (size_t)n_geom * n_tx, n = (size_t)n_rays;
     DevBuf g, xa, za, al, zf, ws, o8, t4, tt, lx, sb;
@@ -215,6 +225,7 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
 {
     int st = check_solve(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, n_rays, x_rx, n_rx, z_land, tt, flags);
     if (st) return st;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_geom * n_tx * n_rx;
     DevBuf g, xa, za, al, rx, ws, dt, da, dta, daa, dn;
@@ -280,6 +291,7 @@ int rtus_match(const double* land_x, const double* tof, int n_batch, int n_rays,
     int st = check_match(land_x, n_batch, n_rays, x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (tof_hit && !tof) return RTUS_ERR_INVALID_ARG;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays, re = (size_t)n_batch * n_rx;
     DevBuf lx, tf, rx, fr, hb, th;
@@ -304,6 +316,7 @@ int rtus_ray_hits(const double* land_x, int n_batch, int n_rays, const double* x
     int st = check_match(land_x, n_batch, n_rays, x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!ray_hit) return RTUS_ERR_INVALID_ARG;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays;
     DevBuf lx, rx, rh;
@@ -349,6 +362,7 @@ int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* 
 {
     int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
     if (st) return st;
+    DeviceGuard device_guard_;
     if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_e * n_f;
     DevBuf dxe, dze, dxf, dzf, dtt, dit;
