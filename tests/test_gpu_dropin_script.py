@@ -1,0 +1,28 @@
+"""GPU: the drop-in claim end to end — a script structured like the reference's main_compare.py (constants as
+globals of __main__, no explicit Params) runs on rtus.shoot_rays and regenerates the reference's compare.csv."""
+import csv
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_compare_like_script_regenerates_compare_csv(tmp_path):
+    out = tmp_path / "compare.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "scripts", "compare_like_main.py"), str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = list(csv.reader(open(out, newline="")))
+    exp = list(csv.reader(open(os.path.join(GOLDEN, "compare.csv"), newline="")))
+    assert got[0] == exp[0] and len(got) == len(exp) == 1811
+    for g, e in zip(got[1:], exp[1:]):
+        assert g[:4] == e[:4]                                   # alpha, offset, radius, hitted: identical text
+        for a, b in zip(g[4:], e[4:]):
+            assert (a == "nan") == (b == "nan")
+            if a != "nan":
+                assert abs(float(a) - float(b)) < 1e-15
