@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s (element x focal-point travel-time solves per second) on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
-the default workload is BASELINE.json configs[1] — 128-element linear array, 1 planar
-interface, 128x128 focal grid, fp64 — i.e. 2,097,152 Fermat travel-time solves per step per GPU
-(rtus_tt_layers_dev, csrc/rtus_fermat.hip).  With --gpus N > 1 (launched by torch.distributed.run,
-one rank per GPU) every rank solves its own 128-element block of a 128*N-element aperture
-(weak scaling) and the [128*N, 16384] travel-time matrix is reassembled on every rank by an RCCL
-all-gather that overlaps the next step's kernel.
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM.  The default
+workload is BASELINE.json configs[1] — 128-element linear array, 1 planar interface, 128x128 focal grid,
+fp64 — i.e. 2,097,152 Fermat travel-time solves per step per GPU (rtus_tt_layers_dev,
+csrc/rtus_fermat.hip).  The K timed steps are K back-to-back launches on one stream, captured once into a
+hipGraph and replayed (--graph off: eager launches).
 
-Other workloads (--workload): ref_sweep (the reference's own sweep, main_rt.py:464-501: 210
-geometries x 905 rays forward trace + 65-element matcher), ref_scale (reference geometry,
-1024 tx x 8192 rays), cfg3_planar (256 elements, 2 interfaces, 512x512 grid).
+--gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank solves its own
+128-element block of a 128*N-element aperture (weak scaling; no collective on the compute path).  The
+[128*N, 16384] travel-time matrix is reassembled on every rank by ONE in-place RCCL all-gather after the K
+steps, inside the timed region (--gather end, default); --gather step gathers after every step on a
+double-buffered matrix, overlapped with the next kernel; --gather off never gathers.  (An all-gather per step
+cannot keep up with the kernel: a GPU produces ~1.3 TB/s of results and would have to receive 7x that.)
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as
-the contract asks (8 B written per solve) — and says which bound actually binds (fp64 VALU).
-`cpu_baseline` is the oracle's fp64 CPU port timed on this box's host cores (rank 0, N=1 only).
+Other workloads (--workload): cfg3_planar (configs[2]), cfg4_lens_f32 (configs[3], curved lens, fp32),
+cfg5_fmc (configs[4], FMC table), ref_sweep (the reference's own sweep, main_rt.py:464-501: 210 geometries x
+905 rays forward trace + 65-element matcher), ref_scale (reference geometry, 1024 tx x 8192 rays).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as the contract
+asks (8 B written per solve; `traffic` = PMC-measured HBM bytes per launch from profiles/traffic_r01.json)
+and says which bound actually binds (VALU issue).  `cpu_baseline` is the oracle's fp64 CPU port timed on
+this box's host cores (rank 0, N=1 only); `extra` holds side measurements of the reference-parity path.
 """
 import argparse
 import json
