@@ -24,6 +24,8 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def rtus():
     import rtus as _rtus
+    if not os.path.exists(_rtus.LIB_PATH):          # fresh checkout: compile librtus.so (hipcc cross-compiles gfx950 without a GPU)
+        _rtus.build()
     return _rtus
 
 
