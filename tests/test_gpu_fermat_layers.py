@@ -80,3 +80,20 @@ def test_many_layers_and_grazing(rtus):
     ref = cport.tt_layers(z_if, c, xe, ze, xf, zf)
     assert np.max(np.abs(tt - ref) / ref) < 1e-12
     assert it.max() < 60
+
+
+def test_sources_inside_deeper_layers_and_same_layer_targets(rtus):
+    """Elements below the first interface(s), targets in the element's own layer, extreme offsets."""
+    from oracle import cport
+    z_if, c = [0.005, 0.012, 0.020], [1500.0, 3200.0, 1480.0, 5900.0]
+    xe = np.array([-0.01, 0.0, 0.003, 0.02])
+    ze = np.array([0.0, 0.006, 0.0125, 0.0199])               # layer 0, 1, 2, 2 (just above an interface)
+    rng = np.random.default_rng(21)
+    xf = np.concatenate([rng.uniform(-0.05, 0.05, 300), [0.0, 0.003, 5.0, -5.0]])
+    zf = np.concatenate([rng.uniform(0.0005, 0.03, 300), [0.0061, 0.0126, 0.025, 0.0201]])
+    tt, it = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, return_iters=True)
+    ref = cport.tt_layers(z_if, c, xe, ze, xf, zf)
+    ok = zf[None, :] > ze[:, None]
+    assert np.isnan(tt[~ok]).all()                            # targets not below the source
+    assert np.max(np.abs(tt - ref)[ok] / ref[ok]) < 1e-12
+    assert it.max() < 60
