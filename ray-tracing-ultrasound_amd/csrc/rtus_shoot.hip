@@ -197,6 +197,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         phi_pq = refract_angle(phi_ap, phis, k.c2 / k.c1);             // :345
         a_pq = tan(phi_pq);                                            // :348
     } else {
+#pragma clang fp contract(fast)   // vector-form mode is not bound to NumPy's multiply-then-add rounding
         // Same law without angles.  With t = unit tangent, n = (-tz, tx), v = unit(A - P):
         // sin(theta_1) = sin(phi_ap - phi_n) = -(t.v); theta_2 = asin(eta sin theta_1) (|.|>1 -> NaN = TIR);
         // direction at phi_pq = phi_s - pi/2 + theta_2 is  u = -n cos(theta_2) + t sin(theta_2).
@@ -231,6 +232,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));  // :289-291
         m = tan(phi_l);                                                // :375
     } else {
+#pragma clang fp contract(fast)
         // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
         const double s_2 = slope * slope, inv = 1.0 / (1.0 + s_2);
         lz_u = (2.0 * slope * ux - (1.0 - s_2) * uz) * inv;
@@ -397,6 +399,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         const double phi_last = refract_angle(phi_l, atan2(ldz, ldx), k.c1 / k.c2);   // :398
         a3 = tan(phi_last);                                            // :401
     } else {
+#pragma clang fp contract(fast)
         // sin / cos of alpha_i = atan2(xi, zi) are xi/rho, zi/rho; then the refraction law as above.
         const double rr = 1.0 / sqrt(xi * xi + zi * zi);
         const double si = xi * rr, ci = zi * rr;
