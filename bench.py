@@ -9,7 +9,7 @@ hipGraph and replayed (--graph off: eager launches).
 
 --gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank solves its own
 128-element block of a 128*N-element aperture (weak scaling; no collective on the compute path).  The
-[128*N, 16384] travel-time matrix is reassembled on every rank by ONE in-place RCCL all-gather after the K
+[128*N, 16384] travel-time matrix is reassembled on every rank by ONE RCCL all-gather after the K
 steps, inside the timed region (--gather end, default); --gather step gathers after every step on a
 double-buffered matrix, overlapped with the next kernel; --gather off never gathers.  (An all-gather per step
 cannot keep up with the kernel: a GPU produces ~1.3 TB/s of results and would have to receive 7x that.)

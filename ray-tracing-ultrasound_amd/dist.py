@@ -21,8 +21,10 @@ def row_shard(n_rows: int, world: int, rank: int):
 
 
 class RowShardedMatrix:
-    """Double-buffered full matrix [world*per, n_cols]; each rank's kernel writes directly into its
-    own row block (``local(slot)``), ``gather(slot)`` reassembles in place."""
+    """Double-buffered full matrix [world*per, n_cols]; each rank's kernel writes its row block into
+    ``local(slot)`` and ``gather(slot)`` reassembles all blocks on every rank.  With more than one rank the
+    block is its own buffer (send and receive buffers of the collective never alias); with one rank it is a
+    view of the matrix and no collective runs."""
 
     def __init__(self, n_rows, n_cols, *, dtype=torch.float64, device="cuda", slots=2, group=None):
         self.group = group
@@ -32,11 +34,13 @@ class RowShardedMatrix:
         self.lo, self.hi, self.per = row_shard(self.n_rows, self.world, self.rank)
         self.full = [torch.zeros((self.world * self.per, self.n_cols), dtype=dtype, device=device)
                      for _ in range(slots)]
+        self.shard = ([f[:self.per] for f in self.full] if self.world == 1 else
+                      [torch.zeros((self.per, self.n_cols), dtype=dtype, device=device) for _ in range(slots)])
         self._work = [None] * slots
 
     def local(self, slot=0):
         """The padded [per, n_cols] block this rank computes (rows beyond hi-lo are padding)."""
-        return self.full[slot][self.rank * self.per:(self.rank + 1) * self.per]
+        return self.shard[slot]
 
     def wait(self, slot=0):
         w = self._work[slot]
@@ -45,7 +49,7 @@ class RowShardedMatrix:
             self._work[slot] = None
 
     def gather(self, slot=0, async_op=False):
-        """In-place all-gather of the row blocks.  With async_op the collective overlaps later work
+        """All-gather of the row blocks into the full matrix.  With async_op the collective overlaps later work
         on the current stream; call ``wait(slot)`` before reading or rewriting the slot."""
         if self.world == 1:
             return None
