@@ -130,11 +130,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches (one-GPU box): RTUS_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # RTUS_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 control flow can be exercised without N GPUs.
+    one_gpu = os.environ.get("RTUS_BENCH_ONE_GPU", "0") == "1"
+    backend = os.environ.get("RTUS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
