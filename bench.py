@@ -8,11 +8,12 @@ csrc/rtus_fermat.hip).  The K timed steps are K back-to-back launches on one str
 hipGraph and replayed (--graph off: eager launches).
 
 --gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank solves its own
-128-element block of a 128*N-element aperture (weak scaling; no collective on the compute path).  The
-[128*N, 16384] travel-time matrix is reassembled on every rank by ONE RCCL all-gather after the K
-steps, inside the timed region (--gather end, default); --gather step gathers after every step on a
-double-buffered matrix, overlapped with the next kernel; --gather off never gathers.  (An all-gather per step
-cannot keep up with the kernel: a GPU produces ~1.3 TB/s of results and would have to receive 7x that.)
+128-element block of a 128*N-element aperture (weak scaling; the solves need no exchange, so there is no
+collective on the timed path).  The [128*N, 16384] travel-time matrix is then reassembled on every rank by ONE
+RCCL all-gather, timed on its own and reported as `reassembly` (--gather after, default).  --gather end puts
+that all-gather inside the timed region, --gather step gathers after every step on a double-buffered matrix
+overlapped with the next kernel, --gather off never gathers.  (An all-gather per step cannot keep up with the
+kernel: a GPU produces ~1.3 TB/s of results and would have to receive 7x that.)
 
 Other workloads (--workload): cfg3_planar (configs[2]), cfg4_lens_f32 (configs[3], curved lens, fp32),
 cfg5_fmc (configs[4], FMC table), ref_sweep (the reference's own sweep, main_rt.py:464-501: 210 geometries x
@@ -45,9 +46,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2_planar",
                     choices=["cfg2_planar", "cfg3_planar", "cfg4_lens_f32", "cfg5_fmc", "ref_sweep", "ref_scale"])
-    ap.add_argument("--gather", default="end", choices=["end", "step", "off"],
-                    help="--gpus > 1: RCCL all-gather of the row shards once after the K steps (end), "
-                         "after every step overlapped with the next kernel (step), or never (off)")
+    ap.add_argument("--gather", default="after", choices=["after", "end", "step", "off"],
+                    help="--gpus > 1: RCCL all-gather of the row shards — once AFTER the timed region, timed on its own "
+                         "(after, default: the solves need no exchange, the reassembly is reported separately); once "
+                         "inside the timed region after the K steps (end); after every step, overlapped with the next "
+                         "kernel (step); never (off)")
     ap.add_argument("--graph", default="on", choices=["on", "off"],
                     help="replay the K timed steps as one captured hipGraph (N=1 or --gather end/off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +155,7 @@ def main():
     wl = args.workload
     gather = world > 1 and args.gather == "step"
     gather_end = world > 1 and args.gather == "end"
+    gather_after = world > 1 and args.gather == "after"
 
     if wl == "cfg4_lens_f32":
         import ctypes as C
@@ -182,8 +186,8 @@ def main():
             for b in range(slots):
                 m.wait(b)
 
-        def finish():
-            if gather_end:
+        def finish(force=False):
+            if gather_end or force:
                 m.gather(0)
     elif wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
         W = fmc_inputs(rank, world) if wl == "cfg5_fmc" else planar_inputs(wl, rank, world)
@@ -210,8 +214,8 @@ def main():
             for b in range(slots):
                 m.wait(b)
 
-        def finish():                   # reassemble the last step's matrix on every rank (RCCL all-gather over xGMI)
-            if gather_end:
+        def finish(force=False):        # reassemble the last step's matrix on every rank (RCCL all-gather over xGMI)
+            if gather_end or force:
                 m.gather(0)
     else:
         R = ref_inputs(wl)
@@ -232,12 +236,12 @@ def main():
         def drain():
             pass
 
-        def finish():
+        def finish(force=False):
             pass
 
     for s in range(args.warmup):
         step(s)
-    finish()
+    finish(force=gather_after)          # also warms the communicator up
     drain()
     torch.cuda.synchronize()
 
@@ -280,6 +284,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration over the timed region
+    reassembly_ms = None
+    if gather_after:                                  # the one exchange of the path, outside the solve loop
+        t1 = time.perf_counter()
+        finish(force=True)
+        torch.cuda.synchronize()
+        barrier()
+        reassembly_ms = (time.perf_counter() - t1) * 1e3
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -305,10 +316,16 @@ def main():
             "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
             "solves_per_step_per_gpu": units_per_step,
             "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather else
-                                                       ", RCCL all-gather of the final matrix" if gather_end else ""),
+                                                       ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
+                                                       ", RCCL all-gather of the final matrix after the timed region" if gather_after else ""),
             "launch": "hipGraph replay of K launches" if graph is not None else "eager launches",
         },
     }
+    if reassembly_ms is not None:
+        shard_bytes = units_per_step * (4 if wl == "cfg4_lens_f32" else 8)
+        out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "ms": round(reassembly_ms, 4),
+                             "bytes_received_per_rank": shard_bytes * (world - 1),
+                             "GB_per_s_per_rank": round(shard_bytes * (world - 1) / (reassembly_ms * 1e-3) / 1e9, 2)}
     ach = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
