@@ -315,6 +315,10 @@ def main():
             "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
             "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
             "solves_per_step_per_gpu": units_per_step,
+            "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64)"}.get(
+                wl, "fp64 results (planar solver: max |dt| 3.3e-17 s vs the long-double oracle); its Newton PRE-iteration runs "
+                    "on the fp32 pipe, the result comes from an fp64 evaluation + Fermat expansion"
+                if wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc") else "fp64, reference-compatible arithmetic"),
             "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather else
                                                        ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
                                                        ", RCCL all-gather of the final matrix after the timed region" if gather_after else ""),
