@@ -99,3 +99,14 @@ def test_fails_loudly_without_library(rtus, monkeypatch, tmp_path):
     monkeypatch.setattr(lib_mod, "LIB_PATH", str(tmp_path / "missing.so"))
     with pytest.raises(ImportError):
         lib_mod.lib()
+
+
+def test_header_is_plain_c():
+    """include/rtus.h must be consumable by a C compiler (C ABI: no C++ or HIP types in the signatures)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(ROOT, "include", "rtus.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
