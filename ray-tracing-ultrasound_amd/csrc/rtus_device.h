@@ -14,6 +14,7 @@
 // Restates the scalar prologue of h_from_alpha / dh_from_alpha (main_rt.py:181-201).
 struct LensK {
     double c1, c2, d;
+    double inv_c1, inv_c2;   // 1/c1, 1/c2 (host-rounded; used by the vector-form mode only)
     double A;        // c1^2/c2^2 - 1                    main_rt.py:183
     double C4A;      // 4*A*C, C = c1^2 T^2 - d^2        main_rt.py:185, 172
     double twoA;     // 2*A                              main_rt.py:173
@@ -27,6 +28,7 @@ static inline LensK make_lens_k(const rtus_lens& L)
 {
     LensK k;
     k.c1 = L.c1; k.c2 = L.c2; k.d = L.d;
+    k.inv_c1 = 1.0 / L.c1; k.inv_c2 = 1.0 / L.c2;
     double T = L.l0 / L.c1 + L.h0 / L.c2;
     double c1sq = L.c1 * L.c1;
     k.A = c1sq / (L.c2 * L.c2) - 1.0;

@@ -167,6 +167,41 @@ __device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int
     return active & unsure;
 }
 
+// ---- cheap reciprocal / square roots for the vector-form (FAST) mode ----------------------------------
+// IEEE fp64 divide / sqrt cost 25 / 36 ns per wave-op (profiles/r01_ubench_fp64.txt); the hardware seeds
+// v_rcp_f64 / v_rsq_f64 (6.8 ns, 5e-8) + Newton steps reach ~1 ulp in ~17 / ~19 ns, and most sqrt+divide
+// pairs of the trace are really one reciprocal square root.  The reference-compatible mode (FAST = false)
+// keeps the correctly rounded operations NumPy uses.
+__device__ __forceinline__ double rcp_fast(double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(y, fma(-b, y, 1.0), y);
+    y = fma(y, fma(-b, y, 1.0), y);
+    return y;                                   // b = 0 / inf / NaN -> NaN (degenerate rays only)
+}
+__device__ __forceinline__ double rsqrt_fast(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);   // cubic step: 5e-8 -> rounding level; x <= 0 -> NaN
+}
+template <bool FAST> __device__ __forceinline__ double m_div(double a, double b) { return FAST ? a * rcp_fast(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ double m_sqrt(double x)
+{
+    if (!FAST) return sqrt(x);
+    const double r = x * rsqrt_fast(x);
+    return x == 0.0 ? 0.0 : r;                  // keeps sqrt(0) = 0 (tangent hits, grazing refraction)
+}
+
+// One segment's travel time, dist / c (main_rt.py:444-445, 497-500).
+template <bool FAST> __device__ __forceinline__ double seg_time(double x1, double z1, double x2, double z2, double c,
+                                                                 double inv_c)
+{
+    if (!FAST) return dist2d(x1, z1, x2, z2) / c;
+    const double dx = x1 - x2, dz = z1 - z2;
+    return m_sqrt<true>(dx * dx + dz * dz) * inv_c;
+}
+
 // Fast-math mode keeps lines in slope form like the reference does; an exactly vertical direction would
 // make the slope infinite where the reference gets tan(pi/2 rounded) = 1.633e16.  Same cap here.
 __device__ __forceinline__ double cap_vertical(double ux, double uz)
@@ -203,11 +238,11 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         // direction at phi_pq = phi_s - pi/2 + theta_2 is  u = -n cos(theta_2) + t sin(theta_2).
         const double2 t = in.tu;
         const double vx = xa - P.x, vz = za - P.y;
-        const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) / sqrt(vx * vx + vz * vz);
-        const double c2 = sqrt(1.0 - s2 * s2);
+        const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) * rsqrt_fast(vx * vx + vz * vz);
+        const double c2 = m_sqrt<true>(1.0 - s2 * s2);
         uz = -t.x * c2 + t.y * s2;
         ux = cap_vertical(t.y * c2 + t.x * s2, uz);
-        a_pq = uz / ux;
+        a_pq = uz * rcp_fast(ux);
     }
     const double b_pq = P.y - a_pq * P.x;                              // :349
 
@@ -215,9 +250,9 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     const double qA = a_pq * a_pq + 1.0;
     const double qB = 2.0 * (a_pq * b_pq - off);
     const double qC = off * off + b_pq * b_pq - r_outer * r_outer;
-    const double sq = sqrt(qB * qB - 4.0 * qA * qC);
+    const double sq = m_sqrt<FAST>(qB * qB - 4.0 * qA * qC);
     const double den = 2.0 * qA;
-    const double xq1 = (-qB + sq) / den, xq2 = (-qB - sq) / den;
+    const double xq1 = m_div<FAST>(-qB + sq, den), xq2 = m_div<FAST>(-qB - sq, den);
     const double zq1 = a_pq * xq1 + b_pq, zq2 = a_pq * xq2 + b_pq;
     const bool upper = zq1 > zq2;
     const double xq = upper ? xq1 : xq2, zq = upper ? zq1 : zq2;
@@ -225,7 +260,8 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // --- reflection on the pipe (main_rt.py:367-376); tangent ignores pipe_offset --
     // RTUS_TRUE_PIPE_TANGENT (not the reference): tangent of the circle where it actually is
     const double xt = (a.flags & RTUS_TRUE_PIPE_TANGENT) ? xq - off : xq;
-    const double slope = -xt / sqrt(r_outer * r_outer - xt * xt);      // :237-238
+    const double slope = FAST ? -xt * rsqrt_fast(r_outer * r_outer - xt * xt)
+                              : -xt / sqrt(r_outer * r_outer - xt * xt);   // :237-238
     double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
     if (!FAST) {
         const double phi_sl = atan(slope);                             // :287
@@ -234,10 +270,10 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     } else {
 #pragma clang fp contract(fast)
         // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
-        const double s_2 = slope * slope, inv = 1.0 / (1.0 + s_2);
+        const double s_2 = slope * slope, inv = rcp_fast(1.0 + s_2);
         lz_u = (2.0 * slope * ux - (1.0 - s_2) * uz) * inv;
         lx_u = cap_vertical(((1.0 - s_2) * ux + 2.0 * slope * uz) * inv, lz_u);
-        m = lz_u / lx_u;
+        m = lz_u * rcp_fast(lx_u);
     }
     const double b = zq - m * xq;                                      // :376
 
@@ -360,12 +396,12 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
             const double y = m * x1 + b;
             if (y >= fmin(y1, y2) - 1e-9 && y <= fmax(y1, y2) + 1e-9) { xi = x1; zi = y; }
         } else {
-            const double m_seg = (y2 - y1) / (x2 - x1);                // :127-128
+            const double m_seg = m_div<FAST>(y2 - y1, x2 - x1);         // :127-128
             const double b_seg = y1 - m_seg * x1;
             if (np_isclose(m, m_seg, 1e-5, 1e-8)) {                    // :131-144
                 if (np_isclose(b, b_seg, 1e-5, 1e-8)) { xi = (x1 + x2) / 2.0; zi = m * xi + b; }
             } else {
-                const double x = (b_seg - b) / (m - m_seg);            // :147
+                const double x = m_div<FAST>(b_seg - b, m - m_seg);     // :147
                 const double y = m * x + b;                            // :150
                 const double xlo = x1 < x2 ? x1 : x2, xhi = x1 < x2 ? x2 : x1;
                 const double ylo = y1 < y2 ? y1 : y2, yhi = y1 < y2 ? y2 : y1;
@@ -401,23 +437,23 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     } else {
 #pragma clang fp contract(fast)
         // sin / cos of alpha_i = atan2(xi, zi) are xi/rho, zi/rho; then the refraction law as above.
-        const double rr = 1.0 / sqrt(xi * xi + zi * zi);
+        const double rr = rsqrt_fast(xi * xi + zi * zi);
         const double si = xi * rr, ci = zi * rr;
         const double B = k.phi_3 * ci - k.twoTc;
-        const double sqd = sqrt(B * B - k.C4A);
-        const double h = (-B - sqd) / k.twoA;
+        const double dsc = B * B - k.C4A, rsqd = rsqrt_fast(dsc), sqd = dsc * rsqd;
+        const double h = -(-B - sqd) * k.phi_1;                         // phi_1 = -1/(2A)
         const double dB = -k.phi_3 * si;
-        const double dh = k.phi_1 * (dB + B * dB / sqd);
+        const double dh = k.phi_1 * (dB + B * dB * rsqd);
         double tz = dh * ci - h * si, tx_ = dh * si + h * ci;          // (dz, dx)
-        const double rt = 1.0 / sqrt(tx_ * tx_ + tz * tz);
+        const double rt = rsqrt_fast(tx_ * tx_ + tz * tz);
         tx_ *= rt; tz *= rt;
         const double s2 = -(k.c1 / k.c2) * (tx_ * lx_u + tz * lz_u);   // u_l is a unit vector
-        const double c2 = sqrt(1.0 - s2 * s2);                         // NaN = total internal reflection
+        const double c2 = m_sqrt<true>(1.0 - s2 * s2);                 // NaN = total internal reflection
         const double w3z = -tx_ * c2 + tz * s2;
-        a3 = w3z / cap_vertical(tz * c2 + tx_ * s2, w3z);
+        a3 = w3z * rcp_fast(cap_vertical(tz * c2 + tx_ * s2, w3z));
     }
     const double b3 = zi - a3 * xi;                                    // :402
-    const double x_in = (zf - b3) / a3;                                // :404
+    const double x_in = m_div<FAST>(zf - b3, a3);                       // :404
 
     out.xq = xq; out.zq = zq; out.xi = xi; out.zi = zi; out.x_in = x_in;
 }
@@ -456,10 +492,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
     if (a.land_x) a.land_x[row * n + r] = x_in;
     if (a.status) a.status[row * n + r] = isnan(xq) ? RTUS_RAY_REF_RAISES : 0;
     if (a.tof4 || a.tof) {
-        const double t1 = dist2d(xa, za, P.x, P.y) / k.c1;             // main_compare.py:514
-        const double t2 = dist2d(P.x, P.y, xq, zq) / k.c2;             // :515
-        const double t3 = dist2d(xq, zq, xi, zi) / k.c2;               // :516
-        const double t4 = dist2d(xi, zi, x_in, zf) / k.c1;             // :517
+        const double t1 = seg_time<FAST>(xa, za, P.x, P.y, k.c1, k.inv_c1);   // main_compare.py:514
+        const double t2 = seg_time<FAST>(P.x, P.y, xq, zq, k.c2, k.inv_c2);   // :515
+        const double t3 = seg_time<FAST>(xq, zq, xi, zi, k.c2, k.inv_c2);     // :516
+        const double t4 = seg_time<FAST>(xi, zi, x_in, zf, k.c1, k.inv_c1);   // :517
         if (a.tof4) {
             double* t = a.tof4 + row * 4 * (size_t)n + r;
             t[0] = t1; t[(size_t)n] = t2; t[2 * (size_t)n] = t3; t[3 * (size_t)n] = t4;
@@ -582,10 +618,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
             }
         }
         const bool root = mine && !dead && fabs(fc) < 1e-9;             // |f| large at convergence: a jump, not a root
-        const double t1 = dist2d(in.xa, in.za, in.P.x, in.P.y) / k.c1;
-        const double t2 = dist2d(in.P.x, in.P.y, o.xq, o.zq) / k.c2;
-        const double t3 = dist2d(o.xq, o.zq, o.xi, o.zi) / k.c2;
-        const double t4 = dist2d(o.xi, o.zi, o.x_in, q.z_land) / k.c1;
+        const double t1 = seg_time<FAST>(in.xa, in.za, in.P.x, in.P.y, k.c1, k.inv_c1);
+        const double t2 = seg_time<FAST>(in.P.x, in.P.y, o.xq, o.zq, k.c2, k.inv_c2);
+        const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
+        const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
         const double T = ((t1 + t2) + t3) + t4;
         if (root) {
             // roots are stored compacted (ascending alpha)
