@@ -63,10 +63,23 @@ __device__ __forceinline__ double rcp_seed(double a)
     return (double)__builtin_amdgcn_rcpf((float)a);
 }
 
+// v_readlane of a double held one-per-lane (the lane index is wave-uniform: an SGPR)
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 // A workgroup = 256 focal points x `eb` consecutive elements (loop).  Besides re-using the layer
 // set-up while ze repeats, the loop gives each lane a CONTINUATION PREDICTOR: the signed solution
-// qs = sign(xf - xe) q is a smooth function of the element position, so the two previous
-// solutions extrapolate the next one to ~1e-3..1e-4 and Newton needs ~2 evaluations instead of ~4.5.
+// qs = sign(xf - xe) q is a smooth function of the element position, so the three previous
+// solutions extrapolate the next one to ~1e-3..1e-4 and Newton needs ~1.5 evaluations instead of ~4.5.
+// The extrapolation weights depend on the element positions only: lane l works them out once for element
+// e0 + l (Lagrange form) and the loop fetches them with v_readlane — three fp32 FMAs per solve.
 // The predictor is only a guess: every iterate is clamped to the rigorous lower bound of the root,
 // from which Newton is monotone, so convergence never depends on the elements being evenly spaced.
 template <int NL, bool ITERS>   // NL = number of layers the medium has (n_if + 1)
@@ -83,20 +96,48 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
     const int lane = threadIdx.x & 63;
     const int el = min(e0 + lane, a.n_e - 1);
     const double xe_v = a.xe[el], ze_v = a.ze[el];
+    // predictor set-up for element e0 + lane: how many predecessors inside this block share its depth
+    // (the history restarts when ze changes), and the extrapolation weights on their solutions.
+    float w1_v = 0.0f, w2_v = 0.0f, w3_v = 0.0f;
+    int info_v;                                            // bits 0-1: 0 no guess, 1 proportional, 2 weights; bit 2: new ze
+    {
+        const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0);
+        const double x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3];
+        const double z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3];     // all loads issued together: one round trip
+        // '&', not '&&': keeps the compiler from sinking a load behind the previous comparison
+        const bool s1 = (lane >= 1) & (z1 == ze_v), s2 = s1 & (lane >= 2) & (z2 == ze_v), s3 = s2 & (lane >= 3) & (z3 == ze_v);
+        const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
+        // branch-free on purpose (selects): a branch here lets the compiler sink the x loads behind it,
+        // which costs the prologue a second memory round trip
+        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d23 = (float)(x2 - x3);
+        const float t1 = (float)(xe_v - x1), t2 = (float)(xe_v - x2), t3 = (float)(xe_v - x3);
+        const bool lin = (hist >= 2) & (x1 != x2);                       // else: duplicate positions, no slope
+        const bool quad = lin & (hist >= 3) & (x3 != x1) & (x3 != x2);   // quadratic through the last three solutions
+        const float r12 = __builtin_amdgcn_rcpf(d12);
+        const float q1 = t2 * t3 * __builtin_amdgcn_rcpf(d12 * d13);
+        const float q2 = -t1 * t3 * __builtin_amdgcn_rcpf(d12 * d23);
+        const float q3 = t1 * t2 * __builtin_amdgcn_rcpf(d13 * d23);
+        w1_v = quad ? q1 : (lin ? t2 * r12 : 0.0f);                      // linear through the last two otherwise
+        w2_v = quad ? q2 : (lin ? -t1 * r12 : 0.0f);
+        w3_v = quad ? q3 : 0.0f;
+        const int mode = lin ? 2 : (hist >= 1 ? 1 : 0);
+        info_v = mode | (hist == 0 ? 4 : 0);
+    }
 
     double h[NL], hr[NL], kk[NL], hc[NL];
-    double inv_cm = 0.0, ze_prev = NAN;
+    double inv_cm = 0.0;
     float hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
-    float qs1 = 0.0f, qs2 = 0.0f, d1_old = 0.0f;          // signed solutions of the two previous elements, their slope
-    double xe1 = 0.0, xe2 = 0.0, xe3 = 0.0;              // positions of the three previous elements
-    int hist = 0;
+    float qs1 = 0.0f, qs2 = 0.0f, qs3 = 0.0f;             // signed solutions of the three previous elements
     bool valid = false;
+    float tau = INFINITY;                                  // relative step below which a lane stops iterating
     for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
-        const double xe = __shfl(xe_v, e - e0), ze = __shfl(ze_v, e - e0);
-        if (!(ze == ze_prev)) {                             // wave-uniform: redo the layer set-up only when ze changes
-            ze_prev = ze;
-            hist = 0;
+        const int li = e - e0;
+        const int info = __builtin_amdgcn_readlane(info_v, li);
+        const double xe = readlane_f64(xe_v, li);
+        if (info & 4) {                                     // wave-uniform: redo the layer set-up only when ze changes
+            const double ze = readlane_f64(ze_v, li);
             valid = zf > ze;
+            tau = valid ? 3e-4f : INFINITY;
             // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
             double cm = 0.0;
             inv_cm = 0.0;
@@ -135,32 +176,28 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         // The loop only has to bring q within ~1e-4 of the root (the fp64 expansion below removes the
         // rest to third order), so it runs on the fp32 pipe: half the issue cost of fp64 and native
         // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise three orders below
-        // the stopping threshold.
+        // the stopping threshold.  Lanes whose target is not below the element (!valid) carry garbage
+        // through the arithmetic (never a step: `big` is masked) and get NaN at the store.
         const float Xf = (float)X;
         // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
-        const float lb = valid ? fmaxf(fmaxf(Xf * rs0f, (Xf - asymf) * rhmf), 0.0f) : 0.0f;
+        const float lb = fmaxf(fmaxf(Xf * rs0f, (Xf - asymf) * rhmf), 0.0f);
         float q = lb;
-        float d1 = 0.0f;                                    // first divided difference of the signed solution
-        if (hist >= 2 && xe1 != xe2) {                      // wave-uniform
-            const float ia = __builtin_amdgcn_rcpf((float)(xe1 - xe2));
-            d1 = (qs1 - qs2) * ia;
-            float pred = fmaf(d1, (float)(xe - xe1), qs1);  // linear extrapolation of the signed solution ...
-            if (hist >= 3 && xe1 != xe3) {                  // ... plus the quadratic term (Newton form)
-                const float dd = (d1 - d1_old) * __builtin_amdgcn_rcpf((float)(xe1 - xe3));
-                pred = fmaf(dd * (float)(xe - xe1), (float)(xe - xe2), pred);
-            }
-            q = fmaxf(fabsf(pred), lb);
-        } else if (hist >= 1) {
-            q = fmaxf(fabsf(qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);   // proportional
+        if ((info & 3) == 2) {                              // wave-uniform
+            const float w1 = readlane_f32(w1_v, li), w2 = readlane_f32(w2_v, li), w3 = readlane_f32(w3_v, li);
+            q = fmaxf(fabsf(fmaf(w1, qs1, fmaf(w2, qs2, w3 * qs3))), lb);
+        } else if ((info & 3) == 1) {                       // one solution so far: scale it with the offset
+            const double xe1 = readlane_f64(xe_v, li - 1);
+            q = fmaxf(fabsf(qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);
         }
-        q = valid ? q : 0.0f;
         float y[NL], rS3 = 0.0f;
         int it = 0;
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
             const float q2 = q * q;
-            float S1 = 0.0f, S3 = 0.0f;
+            y[0] = __builtin_amdgcn_rsqf(fmaf(kkf[0], q2, 1.0f));
+            float S1 = hrf[0] * y[0];
+            float S3 = S1 * (y[0] * y[0]);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
+            for (int i = 1; i < NL; ++i) {
                 y[i] = __builtin_amdgcn_rsqf(fmaf(kkf[i], q2, 1.0f));
                 const float hw = hrf[i] * y[i];
                 S1 += hw;
@@ -170,10 +207,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             const float dq = fmaf(-S1, q, Xf) * rS3;
             // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
             // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
-            const bool small = !(fabsf(dq) > 3e-4f * q) || !valid;
-            if (__all(small)) break;
-            q = small ? q : fmaxf(q + dq, lb);
-            if (ITERS) it += small ? 0 : 1;
+            const bool big = fabsf(dq) > tau * q;           // tau = +inf on !valid lanes: never a step
+            if (!__builtin_amdgcn_ballot_w64(big)) break;
+            q = big ? fmaxf(q + dq, lb) : q;
+            if (ITERS) it += big ? 1 : 0;
         }
         // ---- fp64: accurate T at q + the Fermat expansion in the residual dXr = X - X(q) ----------
         // T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
@@ -201,9 +238,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         }
         // history for the predictor: the root itself, q + dXr / X'(q), signed by the side of the element
         const double qroot = fma(dXr, rA3, qd);
-        qs2 = qs1; xe3 = xe2; xe2 = xe1; d1_old = d1;
-        qs1 = (float)(dxs < 0.0 ? -qroot : qroot); xe1 = xe;
-        ++hist;
+        qs3 = qs2; qs2 = qs1;
+        qs1 = (float)(dxs < 0.0 ? -qroot : qroot);
     }
 }
 

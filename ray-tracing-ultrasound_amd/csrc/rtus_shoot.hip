@@ -137,7 +137,8 @@ struct Walk {
     lanemask pend;           // rays parked on `leaf`
 };
 
-__device__ __forceinline__ bool lane_bit(lanemask m) { return (m >> (threadIdx.x & 63)) & 1ull; }
+// this lane's bit of a wave-uniform mask: the mask itself becomes the v_cndmask / exec operand (no per-lane shift + compare)
+__device__ __forceinline__ bool lane_bit(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // Which rays have the whole box on one side of their line?  pos: every d_j > 0, neg: every d_j < 0.
 __device__ __forceinline__ void certify(const Walk& W, const double4 bx, lanemask& pos, lanemask& neg)
@@ -331,15 +332,20 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         DBG(3);
         // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
         // point: a copy never changes class, so the padding cannot produce a hit).
-        const bool mine = lane_bit(W.pend), cp0 = lane_bit(W.c0pos), cn0 = lane_bit(W.c0neg);
+        const bool mine = lane_bit(W.pend);
+        const lanemask c0zero = ~(W.c0pos | W.c0neg);
         const double2* __restrict__ cp = a.curve + (size_t)W.leaf * 8;
+        double2 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = cp[i];                        // 8 gathers in flight together
         int hit = -1;
 #pragma unroll
         for (int i = 7; i >= 0; --i) {
-            const double2 c = cp[i];
-            const double t = fma(m, c.x, b);
-            const bool differs = cp0 ? !(c.y > t) : (cn0 ? !(c.y < t) : (c.y != t));   // np.sign(d_j) != c0
-            hit = differs ? i : hit;
+            const double t = fma(m, c[i].x, b);
+            // np.sign(d_j) != c0, as lane masks: class + must stay >, class - must stay <, class 0 must stay ==
+            const lanemask differs = (W.c0pos & ~__ballot(c[i].y > t)) | (W.c0neg & ~__ballot(c[i].y < t)) |
+                                     (c0zero & __ballot(c[i].y != t));
+            hit = lane_bit(differs) ? i : hit;
         }
         const bool got = mine && hit >= 0;
         W.idx = got ? W.leaf * 8 + hit - 1 : W.idx;
@@ -382,7 +388,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
                         const double dj = c.y - (m * c.x + b);        // :78-79, NumPy rounding
                         const lanemask hit = __ballot(fabs(dj) <= 1e-8) & ~on_found;   // :86 isclose(diffs, 0)
                         on_found |= hit;
-                        on = ((hit >> (threadIdx.x & 63)) & 1ull) ? j : on;
+                        on = lane_bit(hit) ? j : on;
                     }
                 }
             }
