@@ -124,9 +124,11 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         info_v = mode | (hist == 0 ? 4 : 0);
     }
 
-    double h[NL], hr[NL], kk[NL], hc[NL];
+    // Per-lane layer table, PERMUTED so that slot 0 is the lane's fastest traversed layer: there k = 0 and
+    // w = (1 + k q^2)^(-1/2) = 1 exactly, so slot 0 needs no rsqrt anywhere (hr0, hc0 enter the sums directly).
+    double hr0 = 0.0, hc0 = 0.0, hr[NL], kk[NL], hc[NL];             // slots 1 .. NL-1 of the arrays are used
     double inv_cm = 0.0;
-    float hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
+    float hr0f = 0.0f, hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
     float qs1 = 0.0f, qs2 = 0.0f, qs3 = 0.0f;             // signed solutions of the three previous elements
     bool valid = false;
     float tau = INFINITY;                                  // relative step below which a lane stops iterating
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             valid = zf > ze;
             tau = valid ? 3e-4f : INFINITY;
             // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
-            double cm = 0.0;
+            double cm = 0.0, h[NL], hr_l[NL], hc_l[NL], kk_l[NL];   // _l: in layer order
             inv_cm = 0.0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
@@ -155,20 +157,33 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             for (int i = 0; i < NL; ++i) {
                 const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
                 const double r = fastest ? 1.0 : a.c[i] * inv_cm;
-                hr[i] = h[i] * r;
-                hc[i] = h[i] * a.inv_c[i];
-                kk[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
-                s0 += hr[i];
+                hr_l[i] = h[i] * r;
+                hc_l[i] = h[i] * a.inv_c[i];
+                kk_l[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
+                s0 += hr_l[i];
                 // fastest layer(s): linear term h q; slower layers saturate at h r / sqrt(k) (guess only: raw seed)
                 hm += fastest ? h[i] : 0.0;
-                asym += fastest ? 0.0 : hr[i] * __builtin_amdgcn_rsq(kk[i]);
+                asym += fastest ? 0.0 : hr_l[i] * __builtin_amdgcn_rsq(kk_l[i]);
+            }
+            // slot 0 <-> the first layer whose speed is cm (per lane: which layers a path crosses depends on zf)
+            int jf = 0;
+#pragma unroll
+            for (int i = NL - 1; i >= 1; --i) jf = (a.c[i] == cm) ? i : jf;
+            jf = (a.c[0] == cm) ? 0 : jf;
+            hr0 = hr_l[0]; hc0 = hc_l[0];
+#pragma unroll
+            for (int i = 1; i < NL; ++i) {
+                const bool sw = i == jf;
+                hr0 = sw ? hr_l[i] : hr0;        hc0 = sw ? hc_l[i] : hc0;
+                hr[i] = sw ? hr_l[0] : hr_l[i];  hc[i] = sw ? hc_l[0] : hc_l[i];  kk[i] = sw ? kk_l[0] : kk_l[i];
             }
             // lower-bound reciprocals shaved a little so that lb stays a lower bound under fp32 rounding
             rs0f = __builtin_amdgcn_rcpf((float)s0) * (1.0f - 4e-6f);
             rhmf = __builtin_amdgcn_rcpf((float)hm) * (1.0f - 4e-6f);
             asymf = (float)asym * (1.0f + 4e-6f);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
+            for (int i = 1; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
+            hr0f = (float)hr0;
         }
         const double dxs = xf - xe;
         const double X = fabs(dxs);
@@ -193,9 +208,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         int it = 0;
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
             const float q2 = q * q;
-            y[0] = __builtin_amdgcn_rsqf(fmaf(kkf[0], q2, 1.0f));
-            float S1 = hrf[0] * y[0];
-            float S3 = S1 * (y[0] * y[0]);
+            float S1 = hr0f, S3 = hr0f;                     // slot 0: k = 0, y = 1
 #pragma unroll
             for (int i = 1; i < NL; ++i) {
                 y[i] = __builtin_amdgcn_rsqf(fmaf(kkf[i], q2, 1.0f));
@@ -218,28 +231,31 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         const double qd = (double)q;
         const double q2 = qd * qd;
         const double a1 = 1.0 + q2;
-        const double u = rsqrt_refine(a1, (double)__builtin_amdgcn_rsqf((float)a1));
-        double A1 = 0.0, ST = 0.0;
+        const float us = __builtin_amdgcn_rsqf((float)a1);  // u to 1e-7: seed, and good enough for the 2nd-order term
+        const double u = rsqrt_refine(a1, (double)us);
+        double A1 = hr0, ST = hc0;                          // slot 0: w = 1
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
+        for (int i = 1; i < NL; ++i) {
             const double w = rsqrt_refine(fma(kk[i], q2, 1.0), (double)y[i]);
             A1 = fma(hr[i], w, A1);
             ST = fma(hc[i], w, ST);
         }
         const double dXr = fma(-A1, qd, X);
         const double uc = u * inv_cm;
-        const double rA3 = (double)rS3;                     // 1/X'(q) to 1e-7: only scales the 2nd-order term / the predictor
-        double T = fma(a1 * u, ST, dXr * fma(0.5 * (u * u) * (uc * rA3), dXr, qd * uc));
+        // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr): the inner coefficient only scales the 2nd-order term
+        // (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the 1e-7-accurate seeds.
+        const float s2 = (0.5f * us) * (us * rS3);
+        double T = fma(a1 * u, ST, dXr * (uc * fma((double)s2, dXr, qd)));
         if (!valid) T = NAN;
         if (live) {
             const size_t o = (size_t)e * a.n_f + f;
             a.tt[o] = T;
             if (ITERS) a.iters[o] = (uint8_t)it;
         }
-        // history for the predictor: the root itself, q + dXr / X'(q), signed by the side of the element
-        const double qroot = fma(dXr, rA3, qd);
+        // history for the predictor (fp32): the root itself, q + dXr / X'(q), signed by the side of the element
+        const float qroot = fmaf((float)dXr, rS3, q);
         qs3 = qs2; qs2 = qs1;
-        qs1 = (float)(dxs < 0.0 ? -qroot : qroot);
+        qs1 = dxs < 0.0 ? -qroot : qroot;
     }
 }
 
