@@ -15,9 +15,9 @@
 // Cost model (measured, scripts/ubench_fp64.hip): an fp64 fma/mul/add wave-op costs ~2 ns of SIMD
 // time, v_rsq_f64 / v_rcp_f64 ~6.8 ns (seed accuracy 5e-8), IEEE sqrt ~36 ns, IEEE divide ~25 ns.
 // So the Newton iteration runs entirely on the fp32 pipe (v_fma_f32 ~1 ns, v_rsq_f32 / v_rcp_f32
-// ~3.4 ns): it only has to bring q within 1e-4 of the root — Newton needs neither an exact Jacobian nor
+// ~3.4 ns): it only has to bring q within 3e-4 of the root — Newton needs neither an exact Jacobian nor
 // an exact residual for that — and the fp64 result is produced afterwards; no IEEE sqrt/divide anywhere.
-//   * a lane stops when the step it would take is |dq| <= 1e-4 q; it does NOT take that step, so the
+//   * a lane stops when the step it would take is |dq| <= 3e-4 q; it does NOT take that step, so the
 //     seeds of its last evaluation belong to its q and are refined (one cubic step, ~1 ulp) instead
 //     of being recomputed;
 //   * T at the exact root follows from the Fermat expansion in the residual dXr = X - X(q):
