@@ -42,8 +42,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)   # 2000 x ~10 us: a 20 ms timed region (barrier / graph-launch latency < 1 %)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg2_planar",
                     choices=["cfg2_planar", "cfg3_planar", "cfg4_lens_f32", "cfg5_fmc", "ref_sweep", "ref_scale"])
     ap.add_argument("--gather", default="after", choices=["after", "end", "step", "off"],
