@@ -26,6 +26,7 @@ template <typename R> struct LensFermatArgs {
     R* __restrict__ tt;
     R* __restrict__ alpha_out;   // nullable
     int n_e, n_f, eb;
+    int poly_trig;           // 1: [a_lo, a_hi] lies inside [-1, 1] rad -> sin/cos by polynomial, no range reduction
 };
 
 template <typename R> __device__ __forceinline__ R rsqrt_r(R v);
@@ -37,6 +38,54 @@ template <> __device__ __forceinline__ double rsqrt_r<double>(double v)
     y = fma(y * e, fma(e, 0.375, 0.5), y);                 // cubic step: 1e-7 -> ~1e-21 (rounding-limited)
     return y;
 }
+// 1/v to ~1e-7 through the fp32 pipe: Newton steps, the T polish and the alpha output only multiply small
+// corrections by it (IEEE fp64 divide costs 25 ns per wave-op, this ~7 ns)
+template <typename R> __device__ __forceinline__ R rcp_r(R v) { return (R)__builtin_amdgcn_rcpf((float)v); }
+
+// sin and cos for |a| <= 1 rad (the lens is only defined inside +-50.6 deg, main_rt.py:479): Taylor polynomials
+// in Horner form, truncation 4e-23 (fp64, degree 21/22) / 2e-10 (fp32, degree 11/12) — the generic sincos spends
+// most of its time on a range reduction that is never needed here.
+template <typename R> __device__ __forceinline__ void sincos_poly(R a, R& s, R& c);
+template <> __device__ __forceinline__ void sincos_poly<float>(float a, float& s, float& c)
+{
+    const float x2 = a * a;
+    float ps = fmaf(x2, -2.5052108e-8f, 2.7557319e-6f);     // -1/11!, 1/9!
+    ps = fmaf(x2, ps, -1.9841270e-4f);                       // -1/7!
+    ps = fmaf(x2, ps, 8.3333333e-3f);                        //  1/5!
+    ps = fmaf(x2, ps, -1.6666667e-1f);                       // -1/3!
+    s = fmaf(a * x2, ps, a);
+    float pc = fmaf(x2, 2.0876757e-9f, -2.7557319e-7f);     //  1/12!, -1/10!
+    pc = fmaf(x2, pc, 2.4801587e-5f);                        //  1/8!
+    pc = fmaf(x2, pc, -1.3888889e-3f);                       // -1/6!
+    pc = fmaf(x2, pc, 4.1666667e-2f);                        //  1/4!
+    pc = fmaf(x2, pc, -0.5f);
+    c = fmaf(x2, pc, 1.0f);
+}
+template <> __device__ __forceinline__ void sincos_poly<double>(double a, double& s, double& c)
+{
+    const double x2 = a * a;
+    double ps = fma(x2, -1.9572941063391263e-20, 8.2206352466243295e-18);   // -1/21!, 1/19!
+    ps = fma(x2, ps, -2.8114572543455206e-15);               // -1/17!
+    ps = fma(x2, ps, 7.6471637318198164e-13);                //  1/15!
+    ps = fma(x2, ps, -1.6059043836821613e-10);               // -1/13!
+    ps = fma(x2, ps, 2.5052108385441720e-8);                 //  1/11!
+    ps = fma(x2, ps, -2.7557319223985893e-6);                // -1/9!
+    ps = fma(x2, ps, 1.9841269841269841e-4);                 //  1/7!
+    ps = fma(x2, ps, -8.3333333333333333e-3);                // -1/5!
+    ps = fma(x2, ps, 1.6666666666666666e-1);                 //  1/3!
+    s = fma(-(a * x2), ps, a);
+    double pc = fma(x2, 8.8967913924505741e-22, -4.1103176233121648e-19);   // 1/22!, -1/20!
+    pc = fma(x2, pc, 1.5619206968586225e-16);                //  1/18!
+    pc = fma(x2, pc, -4.7794773323873853e-14);               // -1/16!
+    pc = fma(x2, pc, 1.1470745597729725e-11);                //  1/14!
+    pc = fma(x2, pc, -2.0876756987868100e-9);                // -1/12!
+    pc = fma(x2, pc, 2.7557319223985888e-7);                 //  1/10!
+    pc = fma(x2, pc, -2.4801587301587302e-5);                // -1/8!
+    pc = fma(x2, pc, 1.3888888888888889e-3);                 //  1/6!
+    pc = fma(x2, pc, -4.1666666666666664e-2);                // -1/4!
+    pc = fma(x2, pc, 0.5);
+    c = fma(-x2, pc, 1.0);
+}
 template <typename R> __device__ __forceinline__ void sincos_r(R a, R* s, R* c);
 template <> __device__ __forceinline__ void sincos_r<float>(float a, float* s, float* c) { sincosf(a, s, c); }
 template <> __device__ __forceinline__ void sincos_r<double>(double a, double* s, double* c) { sincos(a, s, c); }
@@ -47,7 +96,8 @@ __device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R
                                           R& gp)
 {
     R s, c;
-    sincos_r<R>(alpha, &s, &c);
+    if (k.poly_trig) sincos_poly<R>(alpha, s, c);           // wave-uniform
+    else sincos_r<R>(alpha, &s, &c);
     const R B = k.phi_3 * c - k.twoTc;                      // main_rt.py:184
     const R B1 = -k.phi_3 * s, B2 = -k.phi_3 * c;           // B', B''
     const R disc = B * B - k.C4A;
@@ -71,6 +121,21 @@ __device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R
        + ((pp - uf * uf) * rf + (fx * p2x + fz * p2z) * rf) * k.c2inv;
 }
 
+template <typename R> __device__ __forceinline__ R readlane_r(R v, int l);
+template <> __device__ __forceinline__ float readlane_r<float>(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+template <> __device__ __forceinline__ double readlane_r<double>(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// A workgroup = 256 targets x `eb` consecutive elements.  The minimiser alpha*(element) is smooth in the element
+// position, so the three previous solutions extrapolate the next start (Lagrange weights from the element
+// positions, worked out once per wave by lane l for element e0 + l and fetched with v_readlane, exactly as in
+// rtus_fermat.hip): from the third element of a block on, Newton starts ~1e-7 rad from the root.
 template <typename R>
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> k)
 {
@@ -82,45 +147,79 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     const int lane = threadIdx.x & 63;
     const int el = min(e0 + lane, k.n_e - 1);
     const R xe_v = k.xe[el], ze_v = k.ze[el];
-    const R tol = sizeof(R) == 4 ? R(1e-5) : R(1e-13);      // |d alpha| at which Newton has converged (rad)
+    float w1_v, w3_v;                                       // Lagrange weights of the newest / oldest solution
+    int mode_v;                                             // 0: no history, 1: previous alpha, 2: extrapolate
+    {
+        const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0);
+        const R x1 = k.xe[b1], x2 = k.xe[b2], x3 = k.xe[b3];
+        const R z1 = k.ze[b1], z2 = k.ze[b2], z3 = k.ze[b3];            // all loads issued together
+        const bool s1 = (lane >= 1) & (z1 == ze_v), s2 = s1 & (lane >= 2) & (z2 == ze_v), s3 = s2 & (lane >= 3) & (z3 == ze_v);
+        const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
+        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d23 = (float)(x2 - x3);
+        const float t1 = (float)(xe_v - x1), t2 = (float)(xe_v - x2), t3 = (float)(xe_v - x3);
+        const bool lin = (hist >= 2) & (x1 != x2);
+        const bool quad = lin & (hist >= 3) & (x3 != x1) & (x3 != x2);
+        const float r12 = __builtin_amdgcn_rcpf(d12);
+        const float q1 = t2 * t3 * __builtin_amdgcn_rcpf(d12 * d13);
+        const float q3 = t1 * t2 * __builtin_amdgcn_rcpf(d13 * d23);
+        w1_v = quad ? q1 : (lin ? t2 * r12 : 0.0f);
+        w3_v = quad ? q3 : 0.0f;
+        mode_v = lin ? 2 : (hist >= 1 ? 1 : 0);
+    }
+    // |d alpha| below which a lane stops iterating (rad).  The step it would have taken is still applied — to alpha
+    // directly and to T through the second-order term below — so what is left is third order: with
+    // |d alpha| <= 1e-8 rad that is ~1e-15 rad and < 1e-25 s in fp64 (measured against the reference rays:
+    // tests/test_gpu_lens_fermat.py).  fp32: 1e-5 rad is the type's resolution of alpha.
+    const R tol = sizeof(R) == 4 ? R(1e-5) : R(1e-8);
     // ... or when the step can no longer lower T noticeably (T is FLAT in alpha near the lens focus — the lens is
     // aplanatic — so alpha is ill-conditioned there while T is not): predicted gain g*step/2 below the type's resolution
     const R tolT = sizeof(R) == 4 ? R(2e-12) : R(1e-21);
 
-    R alpha = R(0.5) * (k.a_lo + k.a_hi);
-    bool have = false;
+    R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements
     for (int e = e0; e < e1; ++e) {
-        const R xa = __shfl(xe_v, e - e0), za = __shfl(ze_v, e - e0);
-        if (!have) {
+        const int li = e - e0;
+        const int mode = __builtin_amdgcn_readlane(mode_v, li);
+        const R xa = readlane_r<R>(xe_v, li), za = readlane_r<R>(ze_v, li);
+        R alpha;
+        if (mode == 2) {                                    // wave-uniform
+            const float w1 = readlane_r<float>(w1_v, li), w3 = readlane_r<float>(w3_v, li);   // w2 = 1 - w1 - w3
+            // differences first: alpha* varies slowly, so the weights (3, -3, 1 on an even pitch) act on small numbers
+            alpha = al1 + ((R)(w1 - 1.0f) * (al1 - al2) + (R)w3 * (al3 - al2));
+        } else if (mode == 1) {
+            alpha = al1;
+        } else {
             // first guess: polar angle of the point where the straight chord A-F meets the lens apex height
             const R hz = -(k.phi_3 - k.twoTc + sqrt((k.phi_3 - k.twoTc) * (k.phi_3 - k.twoTc) - k.C4A)) * k.inv2A;
             const R t = (za - hz) / (za - zf);
             alpha = atan2(xa + t * (xf - xa), hz);
-            have = true;
         }
         alpha = fmin(fmax(alpha, k.a_lo), k.a_hi);
-        R lo = k.a_lo, hi = k.a_hi, T, g, gp;
+        R lo = k.a_lo, hi = k.a_hi, T, g, gp, rgp = R(0);
         bool done = false;
         for (int trip = 0; trip < 80; ++trip) {             // wave-uniform trip count, ballot exit
             lens_time<R>(k, alpha, xa, za, xf, zf, T, g, gp);
             if (g > R(0)) hi = alpha; else lo = alpha;      // T decreases left of the minimum
-            R step = -g / gp;
+            rgp = rcp_r<R>(gp);
+            R step = -g * rgp;
             R next = alpha + step;
             const bool bad = !(gp > R(0)) || !(next > lo) || !(next < hi);
             if (bad) { next = R(0.5) * (lo + hi); step = next - alpha; }
-            const bool small = !(fabs(step) > tol) || !(fabs(g * step) > tolT) || done;
-            if (__all(small)) break;
-            if (!small) alpha = next; else done = true;     // a finished lane keeps its alpha (T, g belong to it)
+            const bool go = fabs(step) > tol && fabs(g * step) > tolT && !done;
+            if (!__builtin_amdgcn_ballot_w64(go)) break;
+            if (go) alpha = next; else done = true;         // a finished lane keeps its alpha (T, g belong to it)
         }
         // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g')
         // (only where Newton converged in the interior; a minimum pinned at an interval end keeps T(alpha))
         const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
-        if (interior) T -= R(0.5) * g * g / gp;
+        const R dal = interior ? -g * rgp : R(0);
+        if (interior) T += R(0.5) * g * dal;
+        const R asol = alpha + dal;
         if (live) {
             const size_t o = (size_t)e * k.n_f + f;
             k.tt[o] = T;
-            if (k.alpha_out) k.alpha_out[o] = interior ? alpha - g / gp : alpha;
+            if (k.alpha_out) k.alpha_out[o] = asol;
         }
+        al3 = al2; al2 = al1; al1 = asol;
     }
 }
 
@@ -135,6 +234,7 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     k.a_lo = (R)a_lo; k.a_hi = (R)a_hi;
     k.xe = xe; k.ze = ze; k.xf = xf; k.zf = zf; k.tt = tt; k.alpha_out = alpha_out;
     k.n_e = n_e; k.n_f = n_f;
+    k.poly_trig = (a_lo >= -1.0 && a_hi <= 1.0) ? 1 : 0;
     const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
     int eb = (int)(wave_solves / (1024LL * 4));
     k.eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
