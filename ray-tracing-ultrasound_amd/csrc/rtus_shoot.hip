@@ -128,44 +128,90 @@ __device__ unsigned long long rtus_dbg[8];
 #endif
 
 struct Walk {
-    double m, b, am, marg;   // per lane: line z = m x + b, |m|, certification margin
-    int idx;                 // per lane: p - 1 (segment idx .. idx+1 holds the first sign change), -1 if none
-    int leaf;                // per lane: 8-point leaf the lane still has to look into
+    // per lane: the ray's line z = m x + b multiplied by sg = +1 / -1 so that "same class as point 0" always
+    // reads d > 0 (multiplying by +-1 is exact: every certification decision is the one the unsigned form makes)
+    double ms, bs, sg, am;
+    double marg;             // certification margin; +inf for rays with d_0 == 0 exactly (class 0 is never certified)
+    int slot;                // per lane: 8-point unit (j >> 3) where the lane left the walk — found there, or parked on it
     int start;               // per lane: polyline points before this index are known to have class c0
-    lanemask c0pos, c0neg;   // class of polyline point 0 per ray (neither bit: d_0 == 0)
-    lanemask found;          // rays that are resolved: p located, or nothing left to look at
-    lanemask pend;           // rays parked on `leaf`
+    lanemask active;         // rays still walking
+    lanemask pend;           // rays parked on the leaf `slot`
 };
 
 // this lane's bit of a wave-uniform mask: the mask itself becomes the v_cndmask / exec operand (no per-lane shift + compare)
 __device__ __forceinline__ bool lane_bit(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// Which rays have the whole box on one side of their line?  pos: every d_j > 0, neg: every d_j < 0.
-__device__ __forceinline__ void certify(const Walk& W, const double4 bx, lanemask& pos, lanemask& neg)
+// Which rays have the whole box on one side of their line?  pos: every point keeps the class of point 0,
+// neg: every point has the opposite class.  Each VALU op reads ONE scalar operand (the box lives in SGPRs and
+// gfx9 VOP3 has a single constant-bus slot — otherwise the compiler adds v_mov's per visit).
+__device__ __forceinline__ void certify(const Walk& W, const double4 bx, double marg, lanemask& pos, lanemask& neg)
 {
-    const double e = bx.z - fma(W.m, bx.x, W.b);         // d at the box centre
-    const double s = fma(W.am, bx.y, bx.w) + W.marg;     // how far d can move inside the box + margin
+    const double e = fma(W.sg, bx.z, -fma(W.ms, bx.x, W.bs));   // sg * d at the box centre
+    const double s = fma(W.am, bx.y, bx.w + marg);               // how far d can move inside the box + margin
     pos = __ballot(e > s);
     neg = __ballot(e < -s);
 }
+// retry pass: points before `start` are known to be class c0
+__device__ __forceinline__ void known_prefix(const Walk& W, int j0, int j1, lanemask& pos, lanemask& neg)
+{
+    const lanemask before = __ballot(j1 <= W.start), partly = __ballot(j0 < W.start) & ~before;
+    pos = (pos | before) & ~partly;
+    neg &= ~(before | partly);
+}
 
-// Visit the box whose first polyline point is j0 (and, on a retry pass, whose last is j1 - 1).
-// Returns the mask of active rays that could not be decided at this box.
-__device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int j1, bool retry, lanemask all)
+// Visit an inner box (first polyline point j0).  Rays certified "opposite" are found (p = j0) and leave the walk;
+// returns the rays that could not be decided here (the caller descends if there are any).
+template <bool RETRY>
+__device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int j1)
 {
     lanemask pos, neg;
-    certify(W, bx, pos, neg);
-    lanemask same = (pos & W.c0pos) | (neg & W.c0neg);                   // all points still class c0
-    lanemask unsure = ~(pos | neg);
-    if (retry) {                                                          // points before `start` are known c0
-        const lanemask before = __ballot(j1 <= W.start), partly = __ballot(j0 < W.start) & ~before;
-        same |= before; unsure = (unsure | partly) & ~before;
+    certify(W, bx, W.marg, pos, neg);
+    if (RETRY) known_prefix(W, j0, j1, pos, neg);
+    const lanemask diff = W.active & neg;
+    W.active &= ~neg;
+    W.slot = lane_bit(diff) ? (j0 >> 3) : W.slot;
+    return W.active & ~pos;
+}
+// Visit a leaf box (8 points, unit U): every ray that is not certified "same" leaves the walk here — found
+// (certified opposite: p = 8 U) or parked on the leaf to look at its points itself.
+template <bool RETRY>
+__device__ __forceinline__ void visit_leaf(Walk& W, const double4 bx, int U)
+{
+    lanemask pos, neg;
+    certify(W, bx, W.marg, pos, neg);
+    if (RETRY) known_prefix(W, U * 8, U * 8 + 8, pos, neg);
+    const lanemask out = W.active & ~pos;
+    W.active &= pos;
+    W.pend |= out & ~neg;
+    W.slot = lane_bit(out) ? U : W.slot;
+}
+
+// One lock-step pass over the box hierarchy (4096 / 512 / 64 / 8 points), boxes in index order.  RETRY = a pass after
+// the first (rays whose parked leaf held no change resume behind it): compiled separately so that the first pass,
+// which is nearly always the only one, carries none of the prefix bookkeeping.
+struct WalkBoxes { const double4* node0; const double4* node1; const double4* node2; const double4* node3; int n0, n1, n2, n3; };
+template <bool RETRY>
+__device__ __forceinline__ void walk_pass(Walk& W, const WalkBoxes& a)
+{
+    const int nT = a.n3 > 0 ? a.n3 : 1;
+    for (int T3 = 0; T3 < nT && W.active; ++T3) {
+        if (a.n3 > 0 && !visit<RETRY>(W, a.node3[T3], T3 * 4096, T3 * 4096 + 4096)) continue;
+        const int S0 = a.n3 > 0 ? T3 * 8 : 0, S1 = a.n3 > 0 ? min(T3 * 8 + 8, a.n2) : a.n2;
+        for (int S = S0; S < S1 && W.active; ++S) {
+            DBG(0);
+            if (!visit<RETRY>(W, a.node2[S], S * 512, S * 512 + 512)) continue;
+            const int B1 = min(S * 8 + 8, a.n1);
+            for (int B = S * 8; B < B1 && W.active; ++B) {
+                DBG(1);
+                if (!visit<RETRY>(W, a.node1[B], B * 64, B * 64 + 64)) continue;
+                const int U1 = min(B * 8 + 8, a.n0);
+                for (int U = B * 8; U < U1; ++U) {
+                    DBG(2);
+                    visit_leaf<RETRY>(W, a.node0[U], U);
+                }
+            }
+        }
     }
-    const lanemask active = all & ~(W.found | W.pend);
-    const lanemask diff = active & ~same & ~unsure;                      // certified, and not class c0: p = j0
-    W.found |= diff;
-    W.idx = lane_bit(diff) ? j0 - 1 : W.idx;
-    return active & unsure;
 }
 
 // ---- cheap reciprocal / square roots for the vector-form (FAST) mode ----------------------------------
@@ -287,54 +333,41 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         xabs = fmax(xabs, fabs(bx.x) + bx.y);
         zabs = fmax(zabs, fabs(bx.z) + bx.w);
     }
+    const WalkBoxes boxes = {a.node0, a.node1, a.node2, a.node3, a.n0, a.n1, a.n2, a.n3};
     Walk W;
-    W.m = m; W.b = b; W.am = fabs(m);
     // 2e-8 >= the reference's isclose(d, 0) atol, so a skipped box can hold no "point on the line"
     // (main_rt.py:86); the relative part is ~450x the worst fp64 rounding of d_j.
-    W.marg = 2e-8 + 1e-13 * (fma(W.am, xabs, fabs(b)) + zabs);
-    W.idx = -1; W.leaf = 0; W.start = 0; W.pend = 0;
-    const lanemask all = __ballot(true);
-    W.found = __ballot(!fin);                      // non-finite lines: nothing to find
+    const double marg0 = 2e-8 + 1e-13 * (fma(fabs(m), xabs, fabs(b)) + zabs);
+    lanemask c0pos, c0neg;                          // class of polyline point 0 per ray (neither bit: d_0 == 0)
     {
         const double2 c0 = a.curve[0];
         const double t0 = fma(m, c0.x, b);
-        W.c0pos = __ballot(c0.y > t0); W.c0neg = __ballot(c0.y < t0);   // np.sign(d_0)
+        c0pos = __ballot(c0.y > t0); c0neg = __ballot(c0.y < t0);       // np.sign(d_0)
     }
+    const lanemask c0zero = ~(c0pos | c0neg);
+    W.sg = lane_bit(c0neg) ? -1.0 : 1.0;
+    W.ms = W.sg * m; W.bs = W.sg * b; W.am = fabs(m);
+    W.marg = lane_bit(c0zero) ? INFINITY : marg0;
+    W.slot = 0; W.start = 0; W.pend = 0;
+    W.active = __ballot(fin);                       // non-finite lines: nothing to find
+    int idx = -1;                                   // p - 1 (segment idx .. idx+1 holds the first sign change), -1 if none
     // Lock-step part: boxes are visited in index order with wave-uniform indices (scalar loads); a ray
     // leaves the walk when a box certifies its answer or when it reaches an 8-point leaf it cannot
     // decide — that leaf it then reads itself (per-lane gather), so the wave never evaluates the
     // union of all 64 rays' leaves point by point.
     for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
-        const bool retry = pass > 0;
-        const int nT = a.n3 > 0 ? a.n3 : 1;
-        for (int T3 = 0; T3 < nT && (all & ~(W.found | W.pend)); ++T3) {
-            if (a.n3 > 0 && !visit(W, a.node3[T3], T3 * 4096, T3 * 4096 + 4096, retry, all)) continue;
-            const int S0 = a.n3 > 0 ? T3 * 8 : 0, S1 = a.n3 > 0 ? min(T3 * 8 + 8, a.n2) : a.n2;
-        for (int S = S0; S < S1 && (all & ~(W.found | W.pend)); ++S) {
-            DBG(0);
-            if (!visit(W, a.node2[S], S * 512, S * 512 + 512, retry, all)) continue;
-            const int B1 = min(S * 8 + 8, a.n1);
-            for (int B = S * 8; B < B1 && (all & ~(W.found | W.pend)); ++B) {
-                DBG(1);
-                if (!visit(W, a.node1[B], B * 64, B * 64 + 64, retry, all)) continue;
-                const int U1 = min(B * 8 + 8, a.n0);
-                for (int U = B * 8; U < U1; ++U) {
-                    DBG(2);
-                    const lanemask park = visit(W, a.node0[U], U * 8, U * 8 + 8, retry, all);
-                    W.pend |= park;
-                    W.leaf = lane_bit(park) ? U : W.leaf;
-                }
-            }
-        }
-        }
-        W.found |= all & ~W.pend;                   // walked off the end: no class change anywhere
+        const lanemask active0 = W.active;
+        if (pass == 0) walk_pass<false>(W, boxes); else walk_pass<true>(W, boxes);
+        // rays a box answered during this pass: p = first point of that box.  Rays still active walked off the
+        // end: no class change anywhere, idx stays -1.
+        idx = lane_bit(active0 & ~W.active & ~W.pend) ? W.slot * 8 - 1 : idx;
+        W.active = 0;
         if (!W.pend) break;
         DBG(3);
         // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
         // point: a copy never changes class, so the padding cannot produce a hit).
         const bool mine = lane_bit(W.pend);
-        const lanemask c0zero = ~(W.c0pos | W.c0neg);
-        const double2* __restrict__ cp = a.curve + (size_t)W.leaf * 8;
+        const double2* __restrict__ cp = a.curve + (size_t)W.slot * 8;
         double2 c[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) c[i] = cp[i];                        // 8 gathers in flight together
@@ -343,19 +376,17 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         for (int i = 7; i >= 0; --i) {
             const double t = fma(m, c[i].x, b);
             // np.sign(d_j) != c0, as lane masks: class + must stay >, class - must stay <, class 0 must stay ==
-            const lanemask differs = (W.c0pos & ~__ballot(c[i].y > t)) | (W.c0neg & ~__ballot(c[i].y < t)) |
+            const lanemask differs = (c0pos & ~__ballot(c[i].y > t)) | (c0neg & ~__ballot(c[i].y < t)) |
                                      (c0zero & __ballot(c[i].y != t));
             hit = lane_bit(differs) ? i : hit;
         }
         const bool got = mine && hit >= 0;
-        W.idx = got ? W.leaf * 8 + hit - 1 : W.idx;
-        W.found |= __ballot(got);
-        W.start = (mine && !got) ? W.leaf * 8 + 8 : W.start;             // nothing here: resume after this leaf
-        W.found &= ~__ballot(mine && !got);
+        idx = got ? W.slot * 8 + hit - 1 : idx;
+        W.start = (mine && !got) ? W.slot * 8 + 8 : W.start;             // nothing here: resume after this leaf
+        W.active = __ballot(mine && !got);
         W.pend = 0;
-        if ((W.found & all) == all) break;
+        if (!W.active) break;
     }
-    const int idx = W.idx;
 
     double xi = NAN, zi = NAN;
     // No sign change anywhere: first polyline point within isclose(d, 0) of the line, else None
@@ -369,16 +400,16 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         int on = -1;
         for (int S = 0; S < a.n2; ++S) {
             lanemask pos, neg;
-            certify(W, a.node2[S], pos, neg);
+            certify(W, a.node2[S], marg0, pos, neg);
             DBG(5);
             if (!(need_on & ~(pos | neg))) continue;
             const int B1 = min(S * 8 + 8, a.n1);
             for (int B = S * 8; B < B1; ++B) {
-                certify(W, a.node1[B], pos, neg);
+                certify(W, a.node1[B], marg0, pos, neg);
                 if (!(need_on & ~(pos | neg))) continue;
                 const int U1 = min(B * 8 + 8, a.n0);
                 for (int U = B * 8; U < U1; ++U) {
-                    certify(W, a.node0[U], pos, neg);
+                    certify(W, a.node0[U], marg0, pos, neg);
                     DBG(6);
                     if (!(need_on & ~(pos | neg))) continue;
                     DBG(7);

@@ -83,3 +83,21 @@ def test_lens_irregular_apertures(rtus):
         one = rtus.travel_time_lens(reg[e:e + 1], ze[e:e + 1], xf, zf, params=p)
         m = interior0[e]
         assert np.max(np.abs(one[0] - tt[e])[m]) < 1e-16, e
+
+
+def test_lens_wide_alpha_interval_uses_generic_trig_and_agrees(rtus):
+    """|alpha| <= 1 rad runs the polynomial sin/cos, a wider search interval the generic sincos: same minima."""
+    p = rtus.Params()
+    xe = (np.arange(12) - 5.5) * 0.5e-3
+    xs, zs = np.meshgrid(np.linspace(-0.003, 0.003, 21), np.linspace(0.035, 0.065, 11))
+    xf, zf = xs.ravel(), zs.ravel()
+    ze = np.full(12, D_PLANE)
+    t0, a0 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, return_alpha=True)
+    t1, a1 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, return_alpha=True, alpha_lo=-1.02, alpha_hi=1.02)
+    m = (np.abs(a0) < 0.85) & np.isfinite(t1)
+    assert m.sum() > 1500
+    assert np.max(np.abs(t0 - t1)[m]) < 1e-16
+    assert np.max(np.abs(a0 - a1)[m]) < 1e-9
+    f0 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, dtype=np.float32)
+    f1 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, dtype=np.float32, alpha_lo=-1.02, alpha_hi=1.02)
+    assert np.max(np.abs(f0.astype(np.float64) - f1)[m]) < 2e-10
