@@ -184,6 +184,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
 #pragma unroll
             for (int i = 1; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
             hr0f = (float)hr0;
+            hc0 = valid ? hc0 : NAN;                        // target not below the element: T = NaN falls out of the sums
         }
         const double dxs = xf - xe;
         const double X = fabs(dxs);
@@ -246,7 +247,6 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         // (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the 1e-7-accurate seeds.
         const float s2 = (0.5f * us) * (us * rS3);
         double T = fma(a1 * u, ST, dXr * (uc * fma((double)s2, dXr, qd)));
-        if (!valid) T = NAN;
         if (live) {
             const size_t o = (size_t)e * a.n_f + f;
             a.tt[o] = T;
