@@ -131,6 +131,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
     float hr0f = 0.0f, hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
     float qs1 = 0.0f, qs2 = 0.0f, qs3 = 0.0f;             // signed solutions of the three previous elements
     bool valid = false;
+    float rS3 = 0.0f;                                      // 1 / X'(q) of the latest Newton evaluation (kept across elements)
     float tau = INFINITY;                                  // relative step below which a lane stops iterating
     for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
         const int li = e - e0;
@@ -201,11 +202,11 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         if ((info & 3) == 2) {                              // wave-uniform
             const float w1 = readlane_f32(w1_v, li), w2 = readlane_f32(w2_v, li), w3 = readlane_f32(w3_v, li);
             q = fmaxf(fabsf(fmaf(w1, qs1, fmaf(w2, qs2, w3 * qs3))), lb);
-        } else if ((info & 3) == 1) {                       // one solution so far: scale it with the offset
-            const double xe1 = readlane_f64(xe_v, li - 1);
-            q = fmaxf(fabsf(qs1) * Xf * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)(xf - xe1)), 1e-30f)), lb);
+        } else if ((info & 3) == 1) {                       // one solution so far: first-order Taylor step from it —
+            const double xe1 = readlane_f64(xe_v, li - 1);  // d(qs)/d(xe) = -1 / X'(q), which the last solve left in rS3
+            q = fmaxf(fabsf(fmaf(-rS3, (float)(xe - xe1), qs1)), lb);
         }
-        float y[NL], rS3 = 0.0f;
+        float y[NL];
         int it = 0;
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
             const float q2 = q * q;
