@@ -22,7 +22,8 @@ cfg5_fmc (configs[4], FMC table), ref_sweep (the reference's own sweep, main_rt.
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as the contract
 asks (8 B written per solve; `traffic` = PMC-measured HBM bytes per launch from profiles/traffic_r01.json)
 and says which bound actually binds (VALU issue).  `cpu_baseline` is the oracle's fp64 CPU port timed on
-this box's host cores (rank 0, N=1 only); `extra` holds side measurements of the reference-parity path.
+this box's host cores (rank 0, N=1 only); `extra` holds side measurements: the reference-parity path, the same
+planar kernel on configs[2] and the curved-lens kernel of configs[3].
 """
 import argparse
 import json
@@ -458,6 +459,25 @@ def extra_ref_path(dev_api, rtus, t64, torch):
         dt = (time.perf_counter() - t0) / k
         res[kind + ("_fastmath" if fast else "")] = {"Mrays_per_s": round(G * T * N / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4),
                      "rays_per_pass": G * T * N}
+    # the same planar kernel on BASELINE configs[2] (256 elements, 2 interfaces, 512 x 512 grid): a launch large
+    # enough (537 MB of results) that launch overhead and ramp no longer weigh on the HBM fraction
+    W = planar_inputs("cfg3_planar", 0, 1)
+    out3 = torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device="cuda")
+    plan3 = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=out3)
+    for _ in range(3):
+        plan3.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        plan3.run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms3 = e0.elapsed_time(e1) / 20
+    n3 = W["n_e"] * W["n_f"]
+    res["cfg3_planar"] = {"Mrays_per_s": round(n3 / ms3 / 1e3, 1), "ms_per_launch": round(ms3, 4), "solves_per_launch": n3,
+                          "hbm_frac": round(n3 * 8 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del out3, plan3
     # curved-lens two-point Fermat solves (BASELINE config 4 geometry: 1024 elements over the reference lens,
     # 1024 x 256 target strip inside the insonified cone), fp64 and fp32
     import ctypes as C
