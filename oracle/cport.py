@@ -113,7 +113,8 @@ def ray_hits(target_x, x_rx, atol, rtol=1e-5):
 
 
 def tt_layers(z_if, c, xe, ze, xf, zf):
-    """Planar-layer Fermat travel times [n_e, n_f] by long-double bisection (parity unpinned)."""
+    """Planar-layer Fermat travel times [n_e, n_f] by long-double bisection (parity unpinned w.r.t. the reference,
+    which has no planar interfaces; pinned bit for bit to 50-digit values: tests/golden/planar_mp.npz)."""
     z_if, c, xe, ze, xf, zf = map(_f64, (z_if, c, xe, ze, xf, zf))
     tt = np.empty((xe.size, xf.size), dtype=np.float64)
     lib().orc_tt_layers(z_if, c, z_if.size, xe, ze, xe.size, xf, zf, xf.size, tt)

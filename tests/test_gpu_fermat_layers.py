@@ -97,3 +97,18 @@ def test_sources_inside_deeper_layers_and_same_layer_targets(rtus):
     assert np.isnan(tt[~ok]).all()                            # targets not below the source
     assert np.max(np.abs(tt - ref)[ok] / ref[ok]) < 1e-12
     assert it.max() < 60
+
+
+def test_gpu_vs_50_digit_values(rtus):
+    """GPU solver against the 50-digit mpmath values (tests/golden/planar_mp.npz, see make_planar_mp.py): the check
+    that does not go through the C oracle at all.  Tolerance 2e-15 relative (observed ~1e-16: the Fermat
+    expansion's O(dX^3) remainder plus a few roundings)."""
+    from conftest import load_golden
+    g = load_golden("planar_mp.npz")
+    for name in ("cfg2", "cfg3", "deep", "inner"):
+        a = [g[f"{name}_{k}"] for k in ("z_if", "c", "xe", "ze", "xf", "zf")]
+        ref = g[f"{name}_tt"]
+        m = np.isfinite(ref)
+        tt = rtus.travel_time_layers(*a)
+        assert np.array_equal(np.isnan(tt), ~m), name
+        assert np.max(np.abs(tt - ref)[m] / ref[m]) < 2e-15, name

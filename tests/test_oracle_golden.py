@@ -168,3 +168,23 @@ def test_oracle_root_find_reproduces_scan_hits():
             checked += 1
         assert np.nanmin(tt) >= np.nanmin(ta) - 1e-18
     assert checked > 80
+
+
+def test_planar_oracle_vs_50_digit_values():
+    """The planar-layer solves cannot be pinned to the reference (it has no planar interfaces), but their
+    arithmetic can: tests/golden/planar_mp.npz holds travel times from a 50-digit mpmath solve of Snell's law in
+    the ray parameter p (tests/golden/make_planar_mp.py) — a formulation and a number system independent of the
+    oracle's long-double bisection in q = tan(theta).  684 solves: cfg2 / cfg3 media, a 9-layer medium with
+    near-critical rays, elements inside deeper layers.  Tolerance: 1 ulp of float64 (observed: bit-identical);
+    the fp64 Newton CPU port used as bench.py's cpu_baseline: 1e-15 relative."""
+    from oracle import cport
+    g = load_golden("planar_mp.npz")
+    for name in ("cfg2", "cfg3", "deep", "inner"):
+        a = [g[f"{name}_{k}"] for k in ("z_if", "c", "xe", "ze", "xf", "zf")]
+        ref = g[f"{name}_tt"]
+        m = np.isfinite(ref)
+        assert m.sum() >= 55
+        for fn, tol in ((cport.tt_layers, 2.3e-16), (cport.tt_layers_newton, 1e-15)):
+            tt = fn(*a)
+            assert np.array_equal(np.isnan(tt), ~m), name
+            assert np.max(np.abs(tt - ref)[m] / ref[m]) < tol, (name, fn.__name__)
