@@ -15,7 +15,7 @@ SHORT="--steps 20 --warmup 5 --graph off --no-extra --no-cpu-baseline"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 echo "[1/7] un-profiled default bench";   python3 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "[2/7] kernel trace of the default bench"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $B --steps 200 --warmup 20 > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $B > $OUT/kt.log 2>&1
 echo "[3/7] WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE -d $OUT/wr -o wr -- python3 $B $SHORT > $OUT/wr.log 2>&1
 echo "[4/7] FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE -d $OUT/rd -o rd -- python3 $B $SHORT > $OUT/rd.log 2>&1
 echo "[5/7] SQ counters, headline kernel"; rocprofv3 --pmc $SQ -d $OUT/sq -o sq -- python3 $B $SHORT > $OUT/sq.log 2>&1

@@ -101,8 +101,9 @@ def test_sources_inside_deeper_layers_and_same_layer_targets(rtus):
 
 def test_gpu_vs_50_digit_values(rtus):
     """GPU solver against the 50-digit mpmath values (tests/golden/planar_mp.npz, see make_planar_mp.py): the check
-    that does not go through the C oracle at all.  Tolerance 2e-15 relative (observed ~1e-16: the Fermat
-    expansion's O(dX^3) remainder plus a few roundings)."""
+    that does not go through the C oracle at all.  Tolerance |dt| <= 1e-16 s + 5e-12 t: the solver stops Newton
+    within 3e-4 of the root and removes the rest to second order, so its remainder is O((3e-4)^3) relative —
+    3e-17 s on the ~3e-5 s times of configs 2/3 (the bar is 1e-9 s)."""
     from conftest import load_golden
     g = load_golden("planar_mp.npz")
     for name in ("cfg2", "cfg3", "deep", "inner"):
@@ -111,4 +112,5 @@ def test_gpu_vs_50_digit_values(rtus):
         m = np.isfinite(ref)
         tt = rtus.travel_time_layers(*a)
         assert np.array_equal(np.isnan(tt), ~m), name
-        assert np.max(np.abs(tt - ref)[m] / ref[m]) < 2e-15, name
+        err = np.abs(tt - ref)[m]
+        assert np.all(err <= 1e-16 + 5e-12 * ref[m]), (name, float(err.max()), float((err / ref[m]).max()))
