@@ -87,6 +87,16 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def _out(out, shape, dtype, name="out"):
+    """The caller's result buffer (checked) or a fresh pageable one."""
+    if out is None:
+        return np.empty(shape, dtype=dtype)
+    if not isinstance(out, np.ndarray) or out.dtype != np.dtype(dtype) or out.shape != tuple(shape) \
+            or not out.flags.c_contiguous or not out.flags.writeable:
+        raise ValueError(f"{name} must be a writeable C-contiguous {np.dtype(dtype).name} array of shape {tuple(shape)}")
+    return out
+
+
 SHOOT_FAST_MATH = 0x1       # RTUS_SHOOT_FAST_MATH
 TRUE_PIPE_TANGENT = 0x2     # RTUS_TRUE_PIPE_TANGENT  (physically correct; not the reference)
 ANALYTIC_LENS = 0x4         # RTUS_ANALYTIC_LENS      (physically correct; not the reference)
@@ -187,8 +197,10 @@ def ray_hits(land_x, x_rx, atol=1e-4, rtol=1e-5, *, device=0):
     return rh.astype(bool).reshape(lead + (N,))
 
 
-def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, device=0):
+def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None, device=0):
     """Element x focal-point Fermat travel times through horizontal layers -> tt[n_e, n_f].
+
+    ``out``: optional float64 [n_e, n_f] result buffer, returned as ``tt``.
 
     NOT in the reference (no planar interfaces there): parity unpinned, see DESIGN.md.
     """
@@ -199,7 +211,7 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, device=0)
     xe, ze, xf, zf = _f64(xe, "xe"), _f64(ze, "ze"), _f64(xf, "xf"), _f64(zf, "zf")
     if xe.shape != ze.shape or xf.shape != zf.shape:
         raise ValueError("xe/ze and xf/zf must pair up")
-    tt = np.empty((xe.size, xf.size), dtype=np.float64)
+    tt = _out(out, (xe.size, xf.size), np.float64)
     iters = np.empty((xe.size, xf.size), dtype=np.uint8) if return_iters else None
     st = _lib.lib().rtus_tt_layers(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze),
                                    xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), int(device))
@@ -208,7 +220,7 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, device=0)
 
 
 def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, alpha_hi=None, dtype=np.float64,
-                     return_alpha=False, device=0):
+                     return_alpha=False, out=None, device=0):
     """Element x focal-point Fermat travel times through the reference's curved lens surface
     (h(alpha) of main_rt.py:180-189): elements in the lens (c1), targets in the water (c2) -> tt[n_e, n_f].
 
@@ -226,7 +238,7 @@ def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, al
     xe, ze, xf, zf = arr
     if xe.shape != ze.shape or xf.shape != zf.shape or xe.ndim != 1 or xf.ndim != 1:
         raise ValueError("xe/ze and xf/zf must be 1-D and pair up")
-    tt = np.empty((xe.size, xf.size), dtype=dt)
+    tt = _out(out, (xe.size, xf.size), dt)                       # out: optional caller-owned result buffer
     al = np.empty((xe.size, xf.size), dtype=dt) if return_alpha else None
     lens = p.lens()
     fn = _lib.lib().rtus_tt_lens if dt == np.float64 else _lib.lib().rtus_tt_lens_f32

@@ -71,3 +71,24 @@ def test_layers_plan_and_dev_call(rtus):
         dev_api.tt_layers_dev([0.02], [2330.0, 1483.0], a[0].float(), a[1], a[2], a[3])   # wrong dtype
     with pytest.raises(ValueError):
         dev_api.LayersPlan([0.02], [2330.0], *a)                                          # len(c) != len(z_if) + 1
+
+
+
+def test_caller_owned_result_buffer(rtus):
+    """out=: results land in the caller's array (same bits as a fresh one); unsuitable buffers are refused."""
+    xe = (np.arange(16) - 7.5) * 0.6e-3
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 40), np.linspace(0.025, 0.065, 30))
+    a = ([0.02], [2330.0, 1483.0], xe, np.zeros(16), xs.ravel(), zs.ravel())
+    ref = rtus.travel_time_layers(*a)
+    buf = np.empty((16, 1200))
+    got = rtus.travel_time_layers(*a, out=buf)
+    assert got is buf and np.array_equal(got, ref)
+    d = 0.12156646438729327 + 0.08843353561270673
+    la = (xe * 0.1, np.full(16, d), xs.ravel() * 0.2, zs.ravel())
+    r32 = rtus.travel_time_lens(*la, params=rtus.Params(), dtype=np.float32)
+    b32 = np.empty((16, 1200), np.float32)
+    g32 = rtus.travel_time_lens(*la, params=rtus.Params(), dtype=np.float32, out=b32)
+    assert g32 is b32 and np.array_equal(g32, r32, equal_nan=True)
+    for bad in (np.empty((16, 1199)), np.empty((16, 1200), np.float32), np.empty((1200, 16)).T):
+        with pytest.raises(ValueError):
+            rtus.travel_time_layers(*a, out=bad)
