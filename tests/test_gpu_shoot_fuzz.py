@@ -1,0 +1,20 @@
+"""GPU: randomized forward-trace comparison against the C oracle (scripts/fuzz_shoot.py, 40 trials here; the round's
+long run was 300 trials / 6.4 M rays): all hierarchy depths of the crossing search, tangent pipes, zero offset,
+off-centre elements, random launch grids.  NaN masks identical (except the documented noise-decided continuum at
+offset 0 on the axis), |d| <= 1e-9 (1 m + 100 |value|) — ill-conditioned single rays reach ~2e-11, a wrong segment
+would show as >= 1e-5."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fuzz_forward_trace_vs_oracle(rtus):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_shoot.py"), "40", "777"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK: 40 trials" in r.stdout
