@@ -246,7 +246,14 @@ def main():
 
     for s in range(args.warmup):
         step(s)
-    finish(force=gather_after)          # also warms the communicator up
+    gather_error = None
+    try:
+        finish(force=gather_after)      # also warms the communicator up
+    except Exception as exc:            # the timed region needs no collective: keep measuring, report the failure
+        if not gather_after:
+            raise
+        gather_error = repr(exc)
+        print(f"[bench] warm-up all-gather failed: {gather_error}", file=sys.stderr)
     drain()
     torch.cuda.synchronize()
 
@@ -298,12 +305,16 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration over the timed region
     reassembly_ms = None
-    if gather_after:                                  # the one exchange of the path, outside the solve loop
-        t1 = time.perf_counter()
-        finish(force=True)
-        torch.cuda.synchronize()
-        barrier()
-        reassembly_ms = (time.perf_counter() - t1) * 1e3
+    if gather_after and gather_error is None:         # the one exchange of the path, outside the solve loop
+        try:
+            t1 = time.perf_counter()
+            finish(force=True)
+            torch.cuda.synchronize()
+            barrier()
+            reassembly_ms = (time.perf_counter() - t1) * 1e3
+        except Exception as exc:
+            gather_error = repr(exc)
+            print(f"[bench] all-gather failed: {gather_error}", file=sys.stderr)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -344,6 +355,8 @@ def main():
         out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "ms": round(reassembly_ms, 4),
                              "bytes_received_per_rank": shard_bytes * (world - 1),
                              "GB_per_s_per_rank": round(shard_bytes * (world - 1) / (reassembly_ms * 1e-3) / 1e9, 2)}
+    if gather_error is not None:
+        out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "error": gather_error}
     ach = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
