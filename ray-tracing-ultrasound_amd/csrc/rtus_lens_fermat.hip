@@ -90,8 +90,9 @@ template <typename R> __device__ __forceinline__ void sincos_r(R a, R* s, R* c);
 template <> __device__ __forceinline__ void sincos_r<float>(float a, float* s, float* c) { sincosf(a, s, c); }
 template <> __device__ __forceinline__ void sincos_r<double>(double a, double* s, double* c) { sincos(a, s, c); }
 
-// T(alpha), g = dT/dalpha, g' for one (A, F).
-template <typename R>
+// T(alpha), g = dT/dalpha and (WITH_GP) g' for one (A, F).  Without g' the second derivatives h'', P'' are skipped:
+// about a quarter of the arithmetic.
+template <typename R, bool WITH_GP>
 __device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R xa, R za, R xf, R zf, R& T, R& g,
                                           R& gp)
 {
@@ -106,19 +107,21 @@ __device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R
     const R h = -(B + S) * k.inv2A;                         // :171-177 root [1]
     const R BrS = B * rS;
     const R h1 = -B1 * (R(1) + BrS) * k.inv2A;              // :199-212
-    const R h2 = -(B2 * (R(1) + BrS) + B1 * B1 * rS * (R(1) - BrS * BrS)) * k.inv2A;
     const R px = h * s, pz = h * c;                         // :220-221
     const R p1x = h1 * s + pz, p1z = h1 * c - px;           // :231-232
-    const R p2x = h2 * s + R(2) * h1 * c - px, p2z = h2 * c - R(2) * h1 * s - pz;
     const R ax = px - xa, az = pz - za, fx = px - xf, fz = pz - zf;
     const R ra = rsqrt_r<R>(ax * ax + az * az), rf = rsqrt_r<R>(fx * fx + fz * fz);
     const R la = (ax * ax + az * az) * ra, lf = (fx * fx + fz * fz) * rf;
     const R ua = (ax * p1x + az * p1z) * ra, uf = (fx * p1x + fz * p1z) * rf;     // u . P'
-    const R pp = p1x * p1x + p1z * p1z;
     T = la * k.c1inv + lf * k.c2inv;
     g = ua * k.c1inv + uf * k.c2inv;
-    gp = ((pp - ua * ua) * ra + (ax * p2x + az * p2z) * ra) * k.c1inv
-       + ((pp - uf * uf) * rf + (fx * p2x + fz * p2z) * rf) * k.c2inv;
+    if (WITH_GP) {
+        const R h2 = -(B2 * (R(1) + BrS) + B1 * B1 * rS * (R(1) - BrS * BrS)) * k.inv2A;
+        const R p2x = h2 * s + R(2) * h1 * c - px, p2z = h2 * c - R(2) * h1 * s - pz;
+        const R pp = p1x * p1x + p1z * p1z;
+        gp = ((pp - ua * ua) * ra + (ax * p2x + az * p2z) * ra) * k.c1inv
+           + ((pp - uf * uf) * rf + (fx * p2x + fz * p2z) * rf) * k.c2inv;
+    }
 }
 
 template <typename R> __device__ __forceinline__ R readlane_r(R v, int l);
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     const R tolT = sizeof(R) == 4 ? R(2e-12) : R(1e-21);
 
     R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements
+    R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation ...
+    bool rgp_ok = false;                                    // ... usable if that solve ended at an interior minimum
     for (int e = e0; e < e1; ++e) {
         const int li = e - e0;
         const int mode = __builtin_amdgcn_readlane(mode_v, li);
@@ -194,10 +199,20 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             alpha = atan2(xa + t * (xf - xa), hz);
         }
         alpha = fmin(fmax(alpha, k.a_lo), k.a_hi);
-        R lo = k.a_lo, hi = k.a_hi, T, g, gp, rgp = R(0);
+        R lo = k.a_lo, hi = k.a_hi, T, g, gp = R(0);
+        // Extrapolated start and a usable g' in every lane: evaluate T and g only and take the Newton step with the
+        // g' of the previous element (g' varies by ~1e-3 from one element to the next; it only scales a step that is
+        // already below the stopping tolerance).  If any lane's step is not small, the wave runs the full iteration.
+        bool lite = false;
+        if (mode == 2 && !__builtin_amdgcn_ballot_w64(!rgp_ok)) {           // wave-uniform
+            lens_time<R, false>(k, alpha, xa, za, xf, zf, T, g, gp);
+            const R step = -g * rgp;
+            const bool conv = !(fabs(step) > tol) || !(fabs(g * step) > tolT);
+            lite = !__builtin_amdgcn_ballot_w64(!conv);
+        }
         bool done = false;
-        for (int trip = 0; trip < 80; ++trip) {             // wave-uniform trip count, ballot exit
-            lens_time<R>(k, alpha, xa, za, xf, zf, T, g, gp);
+        for (int trip = 0; trip < 80 && !lite; ++trip) {    // wave-uniform trip count, ballot exit
+            lens_time<R, true>(k, alpha, xa, za, xf, zf, T, g, gp);
             if (g > R(0)) hi = alpha; else lo = alpha;      // T decreases left of the minimum
             rgp = rcp_r<R>(gp);
             R step = -g * rgp;
@@ -210,7 +225,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         }
         // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g')
         // (only where Newton converged in the interior; a minimum pinned at an interval end keeps T(alpha))
-        const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
+        const bool interior = lite || (gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT)));
+        if (!lite) rgp_ok = interior;
         const R dal = interior ? -g * rgp : R(0);
         if (interior) T += R(0.5) * g * dal;
         const R asol = alpha + dal;
