@@ -1,5 +1,5 @@
-"""GPU: randomized forward-trace comparison against the C oracle (scripts/fuzz_shoot.py, 40 trials here; the round's
-long run was 300 trials / 6.4 M rays): all hierarchy depths of the crossing search, tangent pipes, zero offset,
+"""GPU: randomized comparisons against the C oracle.  Forward trace (scripts/fuzz_shoot.py, 40 trials here; the
+round's long runs: 900 trials / 18 M rays): all hierarchy depths of the crossing search, tangent pipes, zero offset,
 off-centre elements, random launch grids.  NaN masks identical (except the documented noise-decided continuum at
 offset 0 on the axis), |d| <= 1e-9 (1 m + 100 |value|) — ill-conditioned single rays reach ~2e-11, a wrong segment
 would show as >= 1e-5."""
@@ -18,3 +18,13 @@ def test_fuzz_forward_trace_vs_oracle(rtus):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK: 40 trials" in r.stdout
+
+
+def test_fuzz_planar_layers_vs_oracle(rtus):
+    """scripts/fuzz_layers.py: random media (0-8 interfaces), apertures (shuffled / duplicated / clustered positions,
+    changing depths, elements inside layers), targets and sizes; 60 trials here (long run: 400 trials, 10.7 M solves,
+    worst 4.7e-17 s / 1.9e-12 relative).  NaN masks identical, |dt| <= 1e-16 s + 2e-11 t."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_layers.py"), "60", "31"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK: 60 trials" in r.stdout
