@@ -26,3 +26,25 @@ def test_main_compare_like_script_regenerates_compare_csv(tmp_path):
             assert (a == "nan") == (b == "nan")
             if a != "nan":
                 assert abs(float(a) - float(b)) < 1e-15
+
+
+def test_main_rt_like_sweep_script_regenerates_database_2_csv(tmp_path):
+    """The reference's sweep (main_rt.py:464-504): 210 shoot_rays calls with r_outer / pipe_offset REBOUND as globals
+    of __main__ between calls, element matching in NumPy on the returned dict.  13,650 rows: hit flags and the
+    offset / radius text identical to the reference's database_2.csv, tof_total within 1e-15 s."""
+    out = tmp_path / "database_2.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "scripts", "sweep_like_main_rt.py"), str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = list(csv.reader(open(out, newline="")))
+    exp = list(csv.reader(open(os.path.join(GOLDEN, "database_2.csv"), newline="")))
+    assert got[0] == exp[0] and len(got) == len(exp) == 13651
+    hits = 0
+    for g, e in zip(got[1:], exp[1:]):
+        assert g[:4] == e[:4]                                   # elem_idx, offset, radius, hitted: identical text
+        if g[3] == "True":
+            hits += 1
+            assert abs(float(g[4]) - float(e[4])) < 1e-15
+        else:
+            assert g[4] == e[4] == "0"
+    assert hits == 498
