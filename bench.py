@@ -55,6 +55,10 @@ def parse():
                          "kernel (step); never (off)")
     ap.add_argument("--graph", default="on", choices=["on", "off"],
                     help="replay the K timed steps as one captured hipGraph (N=1 or --gather end/off)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="planar workloads, graph mode: capture the K steps round-robin on this many streams, each with its "
+                         "own output buffer, so that one launch's ramp-up overlaps the previous one's drain (default 1: "
+                         "K back-to-back launches on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the reference-path side measurements")
     return ap.parse_args()
@@ -200,7 +204,7 @@ def main():
         n_e, n_f = W["n_e"], W["n_f"]
         # double-buffered full matrix; each rank's kernel writes straight into its row block
         dist_api = import_module("ray-tracing-ultrasound_amd.dist")
-        slots = 2 if gather else 1
+        slots = 2 if gather else max(1, args.streams)
         m = dist_api.RowShardedMatrix(world * n_e, n_f, device=dev, slots=slots)
         plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)) for b in range(slots)]
         units_per_step = n_e * n_f
@@ -269,8 +273,18 @@ def main():
                 g = torch.cuda.CUDAGraph()
                 # thread_local: other threads (e.g. the RCCL watchdog at --gpus > 1) may keep issuing HIP calls
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    for s in range(args.steps):
-                        step(s)
+                    if args.streams > 1 and wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
+                        subs = [torch.cuda.Stream() for _ in range(args.streams)]     # fork ...
+                        for st in subs:
+                            st.wait_stream(side)
+                        for s in range(args.steps):
+                            with torch.cuda.stream(subs[s % args.streams]):             # step s -> stream / buffer s % S
+                                step(s)
+                        for st in subs:                                                   # ... and join
+                            side.wait_stream(st)
+                    else:
+                        for s in range(args.steps):
+                            step(s)
             torch.cuda.current_stream().wait_stream(side)
             # untimed replays: the first uploads the graph; then keep the GPU busy for PREWARM_MS so that the timed
             # region starts at the sustained clock whatever K is (the clocks of an idle MI355X take a few ms of load
@@ -346,7 +360,8 @@ def main():
             "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather else
                                                        ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
                                                        ", RCCL all-gather of the final matrix after the timed region" if gather_after else ""),
-            "launch": f"hipGraph replay of K launches (after ~{PREWARM_MS:.0f} ms of untimed replays: clock ramp)" if graph is not None
+            "launch": (f"hipGraph replay of K launches on {args.streams} stream(s)" if args.streams > 1 else "hipGraph replay of K launches") +
+                      f" (after ~{PREWARM_MS:.0f} ms of untimed replays: clock ramp)" if graph is not None
                       else "eager launches",
         },
     }
@@ -514,6 +529,39 @@ def extra_ref_path(dev_api, rtus, t64, torch):
     res["cfg3_planar"] = {"Mrays_per_s": round(n3 / ms3 / 1e3, 1), "ms_per_launch": round(ms3, 4), "solves_per_launch": n3,
                           "hbm_frac": round(n3 * 8 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del out3, plan3
+    # the headline workload again, pipelined: the same K = 400 launches captured round-robin on 4 streams with 4 output
+    # buffers, so a launch's ramp-up overlaps its predecessor's drain (what a host feeding a stream of batches would
+    # do).  Kept out of `value`: there the K launches run back-to-back on one stream, which is also what rocprofv3's
+    # per-kernel durations can be compared with.
+    W = planar_inputs("cfg2_planar", 0, 1)
+    a2 = [t64(W[k]) for k in ("xe", "ze", "xf", "zf")]
+    outs = [torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device="cuda") for _ in range(4)]
+    plans = [dev_api.LayersPlan(W["z_if"], W["c"], *a2, out=o) for o in outs]
+    for pl in plans:
+        pl.run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gp = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gp, stream=side, capture_error_mode="thread_local"):
+            subs = [torch.cuda.Stream() for _ in range(4)]
+            for st in subs:
+                st.wait_stream(side)
+            for k in range(400):
+                with torch.cuda.stream(subs[k % 4]):
+                    plans[k % 4].run()
+            for st in subs:
+                side.wait_stream(st)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(8):
+        gp.replay()
+    msp = _best_ms(torch, gp.replay, 1, blocks=5) / 400
+    n2 = W["n_e"] * W["n_f"]
+    res["cfg2_pipelined_4_streams"] = {"Mrays_per_s": round(n2 / msp / 1e3, 1), "us_per_step": round(msp * 1e3, 3),
+                                       "hbm_frac": round(n2 * 8 / (msp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "400 launches round-robin on 4 streams / 4 output buffers in one hipGraph"}
+    del outs, plans, gp
     # curved-lens two-point Fermat solves (BASELINE config 4 geometry: 1024 elements over the reference lens,
     # 1024 x 256 target strip inside the insonified cone), fp64 and fp32
     import ctypes as C

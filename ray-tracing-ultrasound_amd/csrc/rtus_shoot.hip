@@ -637,14 +637,14 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_solve_kernel(SolveArgs q)
             const bool work = ok && !dead && fabs(fc) > 1e-13 && fabs(ah - al) > 1e-13;   // |f| < 0.1 pm or bracket < 1e-13 rad (dT/dalpha ~ 1e-5 s/rad)
             if (!__any(work) && it > 0) break;
             if (work || it == 0) {
-                double cand = (al * fh - ah * fl) / (fh - fl);
+                double cand = m_div<FAST>(al * fh - ah * fl, fh - fl);
                 if (!(cand > fmin(al, ah) && cand < fmax(al, ah))) cand = 0.5 * (al + ah);
                 ac = (work) ? cand : ac;
             }
             double px, pz, dz, dx;
             lens_eval(k, ac, px, pz, dz, dx);                          // main_rt.py:338, 344 at this lane's alpha
             in.P = make_double2(px, pz);
-            if (FAST) { const double rt = 1.0 / sqrt(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+            if (FAST) { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
             else in.phis = atan2(dz, dx);
             trace_ray<FAST>(a, in, o);                                 // all 64 lanes together
             fc = o.x_in - xe;

@@ -19,6 +19,10 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $B > $OUT/kt.log 2>
 echo "[3/7] WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE -d $OUT/wr -o wr -- python3 $B $SHORT > $OUT/wr.log 2>&1
 echo "[4/7] FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE -d $OUT/rd -o rd -- python3 $B $SHORT > $OUT/rd.log 2>&1
 echo "[5/7] SQ counters, headline kernel"; rocprofv3 --pmc $SQ -d $OUT/sq -o sq -- python3 $B $SHORT > $OUT/sq.log 2>&1
+echo "[5b] WRITE_SIZE / FETCH_SIZE, configs[2] (537 MB per launch)"
+SHORT3="--workload cfg3_planar --steps 5 --warmup 2 --graph off --no-extra --no-cpu-baseline"
+rocprofv3 --pmc WRITE_SIZE -d $OUT/wr3 -o wr -- python3 $B $SHORT3 > $OUT/wr3.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/rd3 -o rd -- python3 $B $SHORT3 > $OUT/rd3.log 2>&1
 echo "[6/7] SQ counters, forward trace (reference arithmetic)"
 rocprofv3 --pmc $SQ -d $OUT/sq_shoot0 -o sq -- python3 $ROOT/scripts/run_shoot_once.py 0 > $OUT/sq_shoot0.log 2>&1
 echo "[7/7] SQ counters, forward trace (vector form)"

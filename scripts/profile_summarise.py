@@ -49,6 +49,8 @@ ks = kernel_stats("kt", f"{tag}_bench_cfg2_kernel_stats.csv")
 wr = counters("wr", f"{tag}_pmc_WRITE_SIZE_cfg2.csv")
 rd = counters("rd", f"{tag}_pmc_FETCH_SIZE_cfg2.csv")
 sq = counters("sq", f"{tag}_pmc_sq_cfg2.csv")
+wr3 = counters("wr3", f"{tag}_pmc_WRITE_SIZE_cfg3.csv") if os.path.isdir(os.path.join(src, "wr3")) else {}
+rd3 = counters("rd3", f"{tag}_pmc_FETCH_SIZE_cfg3.csv") if os.path.isdir(os.path.join(src, "rd3")) else {}
 s0 = counters("sq_shoot0", f"{tag}_pmc_shoot_refscale_sq_compat.csv")
 s1 = counters("sq_shoot1", f"{tag}_pmc_shoot_refscale_sq_fast.csv")
 
@@ -68,12 +70,18 @@ traffic = {
     "cfg2_planar": int(round((2 * r_kib + w_kib) * 1024)),
     "algorithmic_bytes_per_launch": alg,
 }
+head3 = [k[0] for k in wr3 if "rtus_tt_layers_kernel<3, false>" in k[0]]
+if head3 and (head3[0], "FETCH_SIZE") in rd3:
+    traffic["cfg3_planar"] = int(round((2 * rd3[(head3[0], "FETCH_SIZE")] + wr3[(head3[0], "WRITE_SIZE")]) * 1024))
+    traffic["cfg3_algorithmic_bytes_per_launch"] = 256 * 262144 * 8 + (2 * 256 + 2 * 262144) * 8
+    traffic["cfg3_FETCH_SIZE_KiB_raw"] = round(rd3[(head3[0], "FETCH_SIZE")], 2)
+    traffic["cfg3_WRITE_SIZE_KiB"] = round(wr3[(head3[0], "WRITE_SIZE")], 2)
 json.dump(traffic, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
 
 print("headline kernel:", head, "calls", ks[head][1], "avg ns", round(ks[head][3], 1))
 print("bench.py HIP-event mean (un-profiled) us:", bench["roofline"]["avg_launch_ms"] * 1e3, " value", bench["value"])
-print("traffic:", traffic["cfg2_planar"], "vs algorithmic", alg)
+print("traffic:", traffic["cfg2_planar"], "vs algorithmic", alg, "| cfg3:", traffic.get("cfg3_planar"), "vs", traffic.get("cfg3_algorithmic_bytes_per_launch"))
 for label, d in (("planar", sq), ("shoot compat", s0), ("shoot fast", s1)):
     for kn in sorted({k[0] for k in d}):
         g = lambda n: d.get((kn, n), float("nan"))
