@@ -529,39 +529,6 @@ def extra_ref_path(dev_api, rtus, t64, torch):
     res["cfg3_planar"] = {"Mrays_per_s": round(n3 / ms3 / 1e3, 1), "ms_per_launch": round(ms3, 4), "solves_per_launch": n3,
                           "hbm_frac": round(n3 * 8 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del out3, plan3
-    # the headline workload again, pipelined: the same K = 400 launches captured round-robin on 4 streams with 4 output
-    # buffers, so a launch's ramp-up overlaps its predecessor's drain (what a host feeding a stream of batches would
-    # do).  Kept out of `value`: there the K launches run back-to-back on one stream, which is also what rocprofv3's
-    # per-kernel durations can be compared with.
-    W = planar_inputs("cfg2_planar", 0, 1)
-    a2 = [t64(W[k]) for k in ("xe", "ze", "xf", "zf")]
-    outs = [torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device="cuda") for _ in range(4)]
-    plans = [dev_api.LayersPlan(W["z_if"], W["c"], *a2, out=o) for o in outs]
-    for pl in plans:
-        pl.run()
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        gp = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gp, stream=side, capture_error_mode="thread_local"):
-            subs = [torch.cuda.Stream() for _ in range(4)]
-            for st in subs:
-                st.wait_stream(side)
-            for k in range(400):
-                with torch.cuda.stream(subs[k % 4]):
-                    plans[k % 4].run()
-            for st in subs:
-                side.wait_stream(st)
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(8):
-        gp.replay()
-    msp = _best_ms(torch, gp.replay, 1, blocks=5) / 400
-    n2 = W["n_e"] * W["n_f"]
-    res["cfg2_pipelined_4_streams"] = {"Mrays_per_s": round(n2 / msp / 1e3, 1), "us_per_step": round(msp * 1e3, 3),
-                                       "hbm_frac": round(n2 * 8 / (msp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "note": "400 launches round-robin on 4 streams / 4 output buffers in one hipGraph"}
-    del outs, plans, gp
     # curved-lens two-point Fermat solves (BASELINE config 4 geometry: 1024 elements over the reference lens,
     # 1024 x 256 target strip inside the insonified cone), fp64 and fp32
     import ctypes as C
