@@ -1,0 +1,49 @@
+"""Fuzz of the curved-lens Fermat kernels (fp64 and fp32) against the golden-section oracle (long double, no
+derivatives): random apertures (sorted / shuffled / duplicated positions, small depth jitter in blocks), random
+targets in and around the insonified cone, random sizes.  Interior minima: |dt| <= 1e-15 s (fp64), 2e-10 s (fp32);
+minima pinned at an end of the alpha interval: same end, |dt| <= 1e-12 s.
+
+    gpurun -- python scripts/fuzz_lens.py [n_trials] [seed]
+"""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rtus
+from oracle import cport
+
+D = float(np.float64(0.12156646438729327) + np.float64(0.08843353561270673))
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+w64 = w32 = wedge = 0.0
+solves, t0 = 0, time.time()
+p = rtus.Params()
+for trial in range(trials):
+    n_e = int(rng.choice([1, 2, 3, rng.integers(4, 24), rng.integers(24, 90)]))
+    n_f = int(rng.choice([1, rng.integers(2, 70), rng.integers(70, 400)]))
+    xe = rng.uniform(-0.012, 0.012, n_e)
+    k = rng.integers(0, 3)
+    if k == 0: xe = np.sort(xe)
+    if k == 1: xe = np.resize(np.repeat(xe[: max(1, n_e // 3)], 3), n_e)
+    ze = np.full(n_e, D)
+    if rng.random() < 0.3:
+        ze = D + np.repeat(rng.uniform(-2e-4, 2e-4, (n_e + 7) // 8), 8)[:n_e]
+    xf = rng.uniform(-0.012, 0.012, n_f)
+    zf = rng.uniform(0.025, 0.075, n_f)
+    ref, aref = cport.tt_lens(xe, ze, xf, zf, -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
+    t64, a64 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, return_alpha=True)
+    t32 = rtus.travel_time_lens(xe, ze, xf, zf, params=p, dtype=np.float32).astype(np.float64)
+    if not (np.isfinite(t64).all() and np.isfinite(t32).all()):
+        print(f"NON-FINITE result trial {trial}"); sys.exit(1)
+    interior = (np.abs(aref) < rtus.ALPHA_MAX - 1e-6) & (np.abs(a64) < rtus.ALPHA_MAX - 1e-6)
+    edge = ~interior
+    if interior.any():
+        w64 = max(w64, float(np.max(np.abs(t64 - ref)[interior])))
+        w32 = max(w32, float(np.max(np.abs(t32 - ref)[interior])))
+    if edge.any():
+        wedge = max(wedge, float(np.max(np.abs(t64 - ref)[edge])))
+    if w64 > 1e-15 or w32 > 2e-10 or wedge > 1e-12:
+        print(f"MISMATCH trial {trial} n_e={n_e} n_f={n_f}: fp64 {w64:.2e} fp32 {w32:.2e} edge {wedge:.2e}"); sys.exit(1)
+    solves += t64.size
+    if trial % 25 == 24:
+        print(f"trial {trial + 1}/{trials}: {solves} solves, worst fp64 {w64:.2e} s, fp32 {w32:.2e} s, edge-pinned {wedge:.2e} s, "
+              f"{time.time() - t0:.0f} s", flush=True)
+print(f"OK: {trials} trials, {solves} solves, worst fp64 {w64:.2e} s, fp32 {w32:.2e} s, edge-pinned {wedge:.2e} s")
