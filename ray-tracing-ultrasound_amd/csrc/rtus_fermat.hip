@@ -141,6 +141,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             const double ze = readlane_f64(ze_v, li);
             valid = zf > ze;
             tau = valid ? 3e-4f : INFINITY;
+            qs1 = qs2 = qs3 = 0.0f;                         // a lane may carry NaN history from a depth at which its target was
+                                                            // not below the element; the linear predictor multiplies qs3 by 0
             // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
             double cm = 0.0, h[NL], hr_l[NL], hc_l[NL], kk_l[NL];   // _l: in layer order
             inv_cm = 0.0;
