@@ -43,12 +43,14 @@ struct LayerArgs {
     int eb;                            // elements per workgroup
 };
 
-// Refine a v_rsq seed y ~ a^(-1/2) (rel. error e0 ~ 5e-8) with one cubically convergent step:
-// e = 1 - a y^2,  y <- y (1 + e/2 + 3 e^2/8)   -> error ~ e0^3, i.e. rounding-limited.
+// Refine an fp32-pipe seed y ~ a^(-1/2) (relative error d <= ~1.5e-7: v_rsq_f32 plus the rounding of its argument)
+// with one Newton step in fp64: e = 1 - a y^2,  y <- y (1 + e/2)  -> error 1.5 d^2 <= 4e-14.  On the travel time
+// that is < 2e-18 s — an order below the O(dX^3) remainder of the expansion it feeds — and fp64 instructions are what
+// this kernel is short of (half the fp32 issue rate): the cubic step used before cost one more per square root.
 __device__ __forceinline__ double rsqrt_refine(double a, double y)
 {
     const double e = fma(-a * y, y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
+    return fma(y * e, 0.5, y);
 }
 
 // Seed for a^(-1/2), a >= 1: the fp32 pipe (cvt + v_rsq_f32 + cvt, ~3.6 ns) is cheaper than
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             const double xe1 = readlane_f64(xe_v, li - 1);  // d(qs)/d(xe) = -1 / X'(q), which the last solve left in rS3
             q = fmaxf(fabsf(fmaf(-rS3, (float)(xe - xe1), qs1)), lb);
         }
-        float y[NL];
+        float y[NL], dq = 0.0f;                             // dq: the (small, untaken) Newton step of the last trip
         int it = 0;
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
             const float q2 = q * q;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 S3 = fmaf(hw, y[i] * y[i], S3);
             }
             rS3 = __builtin_amdgcn_rcpf(S3);
-            const float dq = fmaf(-S1, q, Xf) * rS3;
+            dq = fmaf(-S1, q, Xf) * rS3;
             // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
             // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
             const bool big = fabsf(dq) > tau * q;           // tau = +inf on !valid lanes: never a step
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         const double qd = (double)q;
         const double q2 = qd * qd;
         const double a1 = 1.0 + q2;
-        const float us = __builtin_amdgcn_rsqf((float)a1);  // u to 1e-7: seed, and good enough for the 2nd-order term
+        const float us = __builtin_amdgcn_rsqf(fmaf(q, q, 1.0f));   // u to 1e-7 on the fp32 pipe: seed + 2nd-order term
         const double u = rsqrt_refine(a1, (double)us);
         double A1 = hr0, ST = hc0;                          // slot 0: w = 1
 #pragma unroll
@@ -245,20 +247,19 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
             ST = fma(hc[i], w, ST);
         }
         const double dXr = fma(-A1, qd, X);
-        const double uc = u * inv_cm;
-        // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr): the inner coefficient only scales the 2nd-order term
-        // (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the 1e-7-accurate seeds.
+        // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
+        // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
         const float s2 = (0.5f * us) * (us * rS3);
-        double T = fma(a1 * u, ST, dXr * (uc * fma((double)s2, dXr, qd)));
+        const double T = u * fma(inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
         if (live) {
             const size_t o = (size_t)e * a.n_f + f;
             a.tt[o] = T;
             if (ITERS) a.iters[o] = (uint8_t)it;
         }
-        // history for the predictor (fp32): the root itself, q + dXr / X'(q), signed by the side of the element
-        const float qroot = fmaf((float)dXr, rS3, q);
+        // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
+        const float qroot = q + dq;
         qs3 = qs2; qs2 = qs1;
-        qs1 = dxs < 0.0 ? -qroot : qroot;
+        qs1 = __int_as_float((__float_as_int(qroot) & 0x7fffffff) | (__double2hiint(dxs) & 0x80000000));
     }
 }
 
