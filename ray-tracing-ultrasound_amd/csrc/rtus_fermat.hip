@@ -111,8 +111,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
         // branch-free on purpose (selects): a branch here lets the compiler sink the x loads behind it,
         // which costs the prologue a second memory round trip
-        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d23 = (float)(x2 - x3);
-        const float t1 = (float)(xe_v - x1), t2 = (float)(xe_v - x2), t3 = (float)(xe_v - x3);
+        // three differences in fp64, the other three from them on the fp32 pipe (t2 = xe - x2 = t1 + d12, ...)
+        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), t1 = (float)(xe_v - x1);
+        const float d23 = d13 - d12, t2 = t1 + d12, t3 = t1 + d13;
         const bool lin = (hist >= 2) & (x1 != x2);                       // else: duplicate positions, no slope
         const bool quad = lin & (hist >= 3) & (x3 != x1) & (x3 != x2);   // quadratic through the last three solutions
         const float r12 = __builtin_amdgcn_rcpf(d12);
@@ -157,7 +158,6 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 cm = faster ? a.c[i] : cm;
                 inv_cm = faster ? a.inv_c[i] : inv_cm;
             }
-            double s0 = 0.0, hm = 0.0, asym = 0.0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
@@ -165,10 +165,6 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 hr_l[i] = h[i] * r;
                 hc_l[i] = h[i] * a.inv_c[i];
                 kk_l[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
-                s0 += hr_l[i];
-                // fastest layer(s): linear term h q; slower layers saturate at h r / sqrt(k) (guess only: raw seed)
-                hm += fastest ? h[i] : 0.0;
-                asym += fastest ? 0.0 : hr_l[i] * __builtin_amdgcn_rsq(kk_l[i]);
             }
             // slot 0 <-> the first layer whose speed is cm (per lane: which layers a path crosses depends on zf)
             int jf = 0;
@@ -182,13 +178,23 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
                 hr0 = sw ? hr_l[i] : hr0;        hc0 = sw ? hc_l[i] : hc0;
                 hr[i] = sw ? hr_l[0] : hr_l[i];  hc[i] = sw ? hc_l[0] : hc_l[i];  kk[i] = sw ? kk_l[0] : kk_l[i];
             }
-            // lower-bound reciprocals shaved a little so that lb stays a lower bound under fp32 rounding
-            rs0f = __builtin_amdgcn_rcpf((float)s0) * (1.0f - 4e-6f);
-            rhmf = __builtin_amdgcn_rcpf((float)hm) * (1.0f - 4e-6f);
-            asymf = (float)asym * (1.0f + 4e-6f);
 #pragma unroll
             for (int i = 1; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
             hr0f = (float)hr0;
+            // the two lower bounds of a cold start, formed on the fp32 pipe (they are only a starting guess):
+            // X <= s0 q with s0 = X'(0), and X <= hm q + asym — the fastest layer(s) (k = 0) contribute the linear term
+            // h q, every slower layer saturates at h r / sqrt(k).  Shaved so that fp32 rounding keeps them lower bounds.
+            float s0f = hr0f, hmf = hr0f, asf = 0.0f;
+#pragma unroll
+            for (int i = 1; i < NL; ++i) {
+                const bool lin = kkf[i] == 0.0f;
+                s0f += hrf[i];
+                hmf += lin ? hrf[i] : 0.0f;
+                asf += lin ? 0.0f : hrf[i] * __builtin_amdgcn_rsqf(kkf[i]);
+            }
+            rs0f = __builtin_amdgcn_rcpf(s0f) * (1.0f - 4e-6f);
+            rhmf = __builtin_amdgcn_rcpf(hmf) * (1.0f - 4e-6f);
+            asymf = asf * (1.0f + 4e-6f);
             hc0 = valid ? hc0 : NAN;                        // target not below the element: T = NaN falls out of the sums
         }
         const double dxs = xf - xe;
