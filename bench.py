@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s (element x focal-point travel-time solves per second) on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input resident in HBM.  The default
-workload is BASELINE.json configs[1] — 128-element linear array, 1 planar interface, 128x128 focal grid,
-fp64 — i.e. 2,097,152 Fermat travel-time solves per step per GPU (rtus_tt_layers_dev,
-csrc/rtus_fermat.hip).  The K timed steps are K back-to-back launches on one stream, captured once into a
-hipGraph and replayed (--graph off: eager launches).
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM.
 
---gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank solves its own
-128-element block of a 128*N-element aperture (weak scaling; the solves need no exchange, so there is no
-collective on the timed path).  The [128*N, 16384] travel-time matrix is then reassembled on every rank by ONE
-RCCL all-gather, timed on its own and reported as `reassembly` (--gather after, default).  --gather end puts
-that all-gather inside the timed region, --gather step gathers after every step on a double-buffered matrix
-overlapped with the next kernel, --gather off never gathers.  (An all-gather per step cannot keep up with the
-kernel: a GPU produces ~1.3 TB/s of results and would have to receive 7x that.)
+N = 1 (default): BASELINE.json configs[2], the largest single-GPU configuration — 256-element array, 2 planar
+interfaces, 512 x 512 focal grid, fp64 = 67,108,864 Fermat travel-time solves (537 MB of results) per step
+(rtus_tt_layers_dev, csrc/rtus_fermat.hip).  The K timed steps are K back-to-back launches on one stream, captured once
+into a hipGraph and replayed (--graph off: eager launches); the figure does not depend on K (20 steps = 3.6 ms of GPU
+work against ~20 us of launch + sync latency).
 
-Other workloads (--workload): cfg3_planar (configs[2]), cfg4_lens_f32 (configs[3], curved lens, fp32),
-cfg5_fmc (configs[4], FMC table), ref_sweep (the reference's own sweep, main_rt.py:464-501: 210 geometries x
-905 rays forward trace + 65-element matcher), ref_scale (reference geometry, 1024 tx x 8192 rays).
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE.json configs[3] STRONG-scaled — the
+1024-element x 1024 x 1024-target curved-lens table (fp32) with its tx rows sharded 1024/N per GPU.  The solves need no
+exchange, so the timed region is collective-free (`value`); the one exchange of the path, the all-gather that
+reassembles the table on every rank, is timed on its own right after and folded into `value_with_reassembly`
+(K steps + ONE all-gather, what --gather end would time) and `value_reassembled_every_step`.  `extra.cfg5_fmc` does the
+same for configs[4] (2048 x 2048 FMC table, tx rows sharded).  Planar workloads given explicitly (--workload
+cfg2_planar / cfg3_planar) are weak-scaled instead: every rank solves its own element block of an N-times wider aperture.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as the contract
-asks (8 B written per solve; `traffic` = PMC-measured HBM bytes per launch from profiles/traffic_r01.json)
-and says which bound actually binds (VALU issue).  `cpu_baseline` is the oracle's fp64 CPU port timed on
-this box's host cores (rank 0, N=1 only); `extra` holds side measurements: the reference-parity path, the same
-planar kernel on configs[2] and the curved-lens kernel of configs[3].
+Other workloads (--workload): cfg2_planar (configs[1]), cfg4_lens_f32, cfg5_fmc, ref_sweep (the reference's own sweep,
+main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher), ref_scale (reference geometry,
+1024 tx x 8192 rays).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roof as the contract asks
+(algorithmic bytes per launch / HIP-event launch time; `traffic` = PMC-measured HBM bytes per launch from profiles/);
+`roofline_valu` carries what actually binds this scalar root-find (VALU issue; SQ counters from profiles/);
+`cpu_baseline` is the oracle's fp64 CPU port timed on this box's host cores on the whole workload, and `accuracy` the
+measured max |dt| of the GPU result against the long-double oracle on a seeded sample (rank 0, N = 1 only);
+`extra` holds side measurements of the other configs and of the reference-parity path.
 """
 import argparse
 import json
@@ -39,32 +42,53 @@ sys.path.insert(0, ROOT)
 PREWARM_MS = 30.0              # untimed graph replays before the timed region (clock ramp), disclosed in config
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
+PLANAR = ("cfg2_planar", "cfg3_planar", "cfg5_fmc")
+WORKLOADS = ("cfg2_planar", "cfg3_planar", "cfg4_lens_f32", "cfg5_fmc", "ref_sweep", "ref_scale")
+DESCR = {
+    "cfg2_planar": "BASELINE configs[1]: 128-element array, 1 planar interface (z=20 mm, c=2330/1483 m/s), 128x128 focal "
+                   "grid, fp64",
+    "cfg3_planar": "BASELINE configs[2]: 256-element array, 2 planar interfaces (nested root-find), 512x512 focal grid, fp64",
+    "cfg4_lens_f32": "BASELINE configs[3]: 1024-element phased array, curved parametric interface (the reference lens), "
+                     "1024x1024 target grid, fp32, tx rows sharded across the GPUs",
+    "cfg5_fmc": "BASELINE configs[4]: full-matrix-capture 2048x2048 tx/rx travel-time table, 3-layer medium + planar "
+                "reflector, tx rows sharded across the GPUs",
+    "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
+    "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher",
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)   # 2000 x ~10 us: a 20 ms timed region (barrier / graph-launch latency < 1 %)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="cfg2_planar",
-                    choices=["cfg2_planar", "cfg3_planar", "cfg4_lens_f32", "cfg5_fmc", "ref_sweep", "ref_scale"])
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="auto", choices=("auto",) + WORKLOADS,
+                    help="auto: cfg3_planar on one GPU (BASELINE configs[2], the largest single-GPU config), "
+                         "cfg4_lens_f32 strong-scaled on several (BASELINE configs[3])")
     ap.add_argument("--gather", default="after", choices=["after", "end", "step", "off"],
-                    help="--gpus > 1: RCCL all-gather of the row shards — once AFTER the timed region, timed on its own "
-                         "(after, default: the solves need no exchange, the reassembly is reported separately); once "
-                         "inside the timed region after the K steps (end); after every step, overlapped with the next "
-                         "kernel (step); never (off)")
+                    help="--gpus > 1: RCCL all-gather of the row shards — once AFTER the timed region, timed on its own and "
+                         "folded into value_with_reassembly (after, default); once inside the timed region after the K "
+                         "steps (end); after every step, overlapped with the next kernel (step); never (off)")
     ap.add_argument("--graph", default="on", choices=["on", "off"],
-                    help="replay the K timed steps as one captured hipGraph (N=1 or --gather end/off)")
+                    help="replay the K timed steps as one captured hipGraph (N=1 or --gather after/end/off)")
     ap.add_argument("--streams", type=int, default=1,
                     help="planar workloads, graph mode: capture the K steps round-robin on this many streams, each with its "
-                         "own output buffer, so that one launch's ramp-up overlaps the previous one's drain (default 1: "
-                         "K back-to-back launches on one stream)")
+                         "own output buffer (default 1: K back-to-back launches on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the reference-path side measurements")
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
+    args = ap.parse_args(argv)
+    if args.workload == "auto":
+        args.workload = "cfg3_planar" if args.gpus <= 1 else "cfg4_lens_f32"
+    return args
 
 
 # ------------------------------------------------------------------------------------ workloads
+def scaling_of(wl, world):
+    """configs[3] / configs[4] are BASELINE's multi-GPU shapes: a fixed table whose tx rows are sharded (strong scaling).
+    The single-GPU planar configs, run on several GPUs, keep their per-GPU block (weak scaling)."""
+    return "strong" if wl in ("cfg4_lens_f32", "cfg5_fmc") else "weak"
+
+
 def planar_inputs(cfg, rank, world):
     """cfg2 = 128 elems @0.6 mm on z=0, interface z=20 mm, c=(2330,1483), 128x128
     focal grid over x in [-20,20] mm, z in [25,65] mm; cfg3 = 256 elems @0.3 mm, interfaces at
@@ -78,32 +102,39 @@ def planar_inputs(cfg, rank, world):
     x_all = (np.arange(n_all) - (n_all - 1) / 2.0) * pitch
     xe = x_all[rank * n_e:(rank + 1) * n_e]
     xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, g), np.linspace(zr[0], zr[1], g))
-    return dict(z_if=z_if, c=c, xe=xe, ze=np.zeros(n_e), xf=xs.ravel(), zf=zs.ravel(), n_e=n_e, n_f=g * g)
+    return dict(z_if=z_if, c=c, xe=xe, ze=np.zeros(n_e), xf=xs.ravel(), zf=zs.ravel(), n_e=n_e, n_f=g * g,
+                rows_total=n_all, lo=rank * n_e)
 
 
-def lens_inputs(rank, world):
-    """BASELINE configs[3]: 1024-element array @0.3 mm on z = d over the reference lens h(alpha),
-    water below, 1024 x 1024 target grid inside the insonified cone, fp32; tx rows sharded 1024/world per GPU
-    (this config is a STRONG-scaling shape in BASELINE; here each rank keeps 128 rows = the 8-GPU shard)."""
+def _strong_rows(n_rows, rank, world):
+    per = -(-n_rows // world)
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows), per
+
+
+def lens_inputs(rank, world, n_rows=1024):
+    """BASELINE configs[3]: 1024-element array @0.03 mm on z = d over the reference lens h(alpha),
+    water below, 1024 x 1024 target grid inside the insonified cone, fp32; tx rows sharded 1024/world per GPU (strong
+    scaling: the table is fixed, each rank solves rows [lo, hi))."""
     import rtus
-    n_e = 128
-    x_all = (np.arange(n_e * world) - (n_e * world - 1) / 2.0) * 0.3e-4
+    x_all = (np.arange(n_rows) - (n_rows - 1) / 2.0) * 0.3e-4
+    lo, hi, per = _strong_rows(n_rows, rank, world)
     xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 1024), np.linspace(0.03, 0.07, 1024))
-    return dict(xe=x_all[rank * n_e:(rank + 1) * n_e], ze=np.full(n_e, rtus.Params().d), xf=xs.ravel(), zf=zs.ravel(),
-                n_e=n_e, n_f=xs.size)
+    return dict(xe=x_all[lo:hi], ze=np.full(hi - lo, rtus.Params().d), xf=xs.ravel(), zf=zs.ravel(),
+                n_e=hi - lo, n_f=xs.size, rows_total=n_rows, lo=lo)
 
 
-def fmc_inputs(rank, world):
+def fmc_inputs(rank, world, n_tx=2048):
     """BASELINE configs[4]: 2048 tx x 2048 rx on z = 0, 3 horizontal layers, planar reflector at
-    depth — unfolded about the reflector into a 5-layer one-way problem; each rank owns 256 tx rows."""
+    depth — unfolded about the reflector into a 5-layer one-way problem; tx rows sharded 2048/world per GPU (strong)."""
     z_if, c, z_r = np.array([0.008, 0.020]), np.array([2330.0, 1483.0, 5900.0]), 0.035
     z_m = np.concatenate([z_if, (2.0 * z_r - z_if)[::-1]])
     c_m = np.concatenate([c, c[::-1][1:]])
-    n_e = 256
-    x_tx = (np.arange(n_e * world) - (n_e * world - 1) / 2.0) * 0.3e-3
+    x_tx = (np.arange(n_tx) - (n_tx - 1) / 2.0) * 0.3e-3
     x_rx = (np.arange(2048) - 1023.5) * 0.3e-3
-    return dict(z_if=z_m, c=c_m, xe=x_tx[rank * n_e:(rank + 1) * n_e], ze=np.zeros(n_e), xf=x_rx,
-                zf=np.full(2048, 2.0 * z_r), n_e=n_e, n_f=2048)
+    lo, hi, per = _strong_rows(n_tx, rank, world)
+    return dict(z_if=z_m, c=c_m, xe=x_tx[lo:hi], ze=np.zeros(hi - lo), xf=x_rx, zf=np.full(2048, 2.0 * z_r),
+                n_e=hi - lo, n_f=2048, rows_total=n_tx, lo=lo)
 
 
 def ref_inputs(kind):
@@ -122,9 +153,98 @@ def ref_inputs(kind):
                 x_rx=rtus.reference_elements())
 
 
+def workload_inputs(wl, rank, world):
+    if wl == "cfg4_lens_f32":
+        return lens_inputs(rank, world)
+    if wl == "cfg5_fmc":
+        return fmc_inputs(rank, world)
+    return planar_inputs(wl, rank, world)
+
+
+# ------------------------------------------------------------------------------------ timing helpers
+class Timed:
+    """K steps of `step(s)` as one hipGraph (or eagerly), bracketed as the contract says."""
+
+    def __init__(self, torch, step, steps, streams=1, use_graph=True):
+        self.torch, self.step, self.steps = torch, step, steps
+        self.graph = None
+        if use_graph:
+            try:
+                self.graph = self._capture(streams)
+            except Exception as exc:            # capture unsupported -> eager launches
+                print(f"[bench] hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+
+    def _capture(self, streams):
+        torch = self.torch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            # thread_local: other threads (e.g. the RCCL watchdog at --gpus > 1) may keep issuing HIP calls
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                if streams > 1:
+                    subs = [torch.cuda.Stream() for _ in range(streams)]              # fork ...
+                    for st in subs:
+                        st.wait_stream(side)
+                    for s in range(self.steps):
+                        with torch.cuda.stream(subs[s % streams]):                    # step s -> stream / buffer s % S
+                            self.step(s)
+                    for st in subs:                                                   # ... and join
+                        side.wait_stream(st)
+                else:
+                    for s in range(self.steps):
+                        self.step(s)
+        torch.cuda.current_stream().wait_stream(side)
+        # untimed replays: the first uploads the graph; then keep the GPU busy for PREWARM_MS so that the timed region
+        # starts at the sustained clock whatever K is (an idle MI355X needs a few ms of load to bring its clocks up)
+        t_pre = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t_pre, 1e-5)
+        for _ in range(min(200, int(PREWARM_MS * 1e-3 / one))):
+            g.replay()
+        torch.cuda.synchronize()
+        return g
+
+    def run(self, barrier, tail=None):
+        """-> (wall seconds of the bracketed region, mean launch ms from HIP events on the launch stream)."""
+        torch = self.torch
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()                      # same (current) stream the library launches on
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            for s in range(self.steps):
+                self.step(s)
+        ev1.record()
+        if tail is not None:
+            tail()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, ev0.elapsed_time(ev1) / self.steps
+
+
+def load_profile_json(name):
+    """profiles/<name>: the newest round's file wins (r02 over r01)."""
+    for tag in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", name.format(tag=tag))
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)), os.path.relpath(p, ROOT)
+            except Exception:
+                pass
+    return None, None
+
+
 # ------------------------------------------------------------------------------------ main
-def main():
-    args = parse()
+def main(argv=None):
+    args = parse(argv)
     # the CPU-baseline leg runs an OpenMP port on every host core; idle OpenMP workers must sleep, not spin, while the
     # GPU side measurements that follow are launched from this thread
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -139,6 +259,7 @@ def main():
     import rtus
     from importlib import import_module
     dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    dist_api = import_module("ray-tracing-ultrasound_amd.dist")
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
@@ -160,72 +281,69 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
     wl = args.workload
-    gather = world > 1 and args.gather == "step"
+    scaling = scaling_of(wl, world)
+    gather_step = world > 1 and args.gather == "step"
     gather_end = world > 1 and args.gather == "end"
     gather_after = world > 1 and args.gather == "after"
 
-    if wl == "cfg4_lens_f32":
-        import ctypes as C
-        W = lens_inputs(rank, world)
-        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
-        xe, ze, xf, zf = t32(W["xe"]), t32(W["ze"]), t32(W["xf"]), t32(W["zf"])
+    # ---- the step ---------------------------------------------------------------------------------
+    m = None                                  # RowShardedMatrix of the table workloads
+    if wl in PLANAR or wl == "cfg4_lens_f32":
+        W = workload_inputs(wl, rank, world)
         n_e, n_f = W["n_e"], W["n_f"]
-        dist_api = import_module("ray-tracing-ultrasound_amd.dist")
-        slots = 2 if gather else 1
-        m = dist_api.RowShardedMatrix(world * n_e, n_f, dtype=torch.float32, device=dev, slots=slots)
-        lens = rtus.Params().lens()
-        fn = rtus.lib().rtus_tt_lens_f32_dev
-        units_per_step = n_e * n_f
-        alg_bytes = units_per_step * 4 + (2 * n_e + 2 * n_f) * 4
-        kernel = "rtus_tt_lens_kernel<float>"
+        f32 = wl == "cfg4_lens_f32"
+        tdt = torch.float32 if f32 else torch.float64
+        slots = 2 if gather_step else (max(1, args.streams) if wl in PLANAR else 1)
+        m = dist_api.RowShardedMatrix(W["rows_total"], n_f, dtype=tdt, device=dev, slots=slots)
+        if m.per < n_e or (scaling == "strong" and (m.lo, m.hi) != (W["lo"], W["lo"] + n_e)):
+            raise SystemExit("row sharding of the inputs and of the matrix disagree")
+        units_per_step = n_e * n_f                       # this rank's solves per step
+        total_units_per_step = W["rows_total"] * n_f     # all ranks
+        word = 4 if f32 else 8
+        alg_bytes = units_per_step * word + (2 * n_e + 2 * n_f) * word
+        if f32:
+            import ctypes as C
+            t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+            xe, ze, xf, zf = t32(W["xe"]), t32(W["ze"]), t32(W["xf"]), t32(W["zf"])
+            lens = rtus.Params().lens()
+            fn = rtus.lib().rtus_tt_lens_f32_dev
+            kernel = "rtus_tt_lens_kernel<float>"
+
+            def launch(b):
+                st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, xf.data_ptr(),
+                        zf.data_ptr(), n_f, m.local(b).data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                assert st == 0
+        else:
+            xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
+            plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)[:n_e]) for b in range(slots)]
+            kernel = f"rtus_tt_layers_kernel<{len(W['c'])}, false>"
+
+            def launch(b):
+                plans[b].run()
 
         def step(s):
             b = s % slots
-            if gather:
-                m.wait(b)
-            st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, xf.data_ptr(),
-                    zf.data_ptr(), n_f, m.local(b).data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-            assert st == 0
-            if gather:
-                m.gather(b, async_op=True)
-
-        def drain():
-            for b in range(slots):
-                m.wait(b)
-
-        def finish(force=False):
-            if gather_end or force:
-                m.gather(0)
-    elif wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
-        W = fmc_inputs(rank, world) if wl == "cfg5_fmc" else planar_inputs(wl, rank, world)
-        xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
-        n_e, n_f = W["n_e"], W["n_f"]
-        # double-buffered full matrix; each rank's kernel writes straight into its row block
-        dist_api = import_module("ray-tracing-ultrasound_amd.dist")
-        slots = 2 if gather else max(1, args.streams)
-        m = dist_api.RowShardedMatrix(world * n_e, n_f, device=dev, slots=slots)
-        plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)) for b in range(slots)]
-        units_per_step = n_e * n_f
-        alg_bytes = units_per_step * 8 + (2 * n_e + 2 * n_f) * 8
-        kernel = f"rtus_tt_layers_kernel<{len(W['c'])}, false>"
-
-        def step(s):
-            b = s % slots
-            if gather:
+            if gather_step:
                 m.wait(b)               # the slot's previous all-gather must finish before it is rewritten
-            plans[b].run()
-            if gather:
+            launch(b)
+            if gather_step:
                 m.gather(b, async_op=True)      # RCCL, overlaps the next step's kernel
 
         def drain():
             for b in range(slots):
                 m.wait(b)
 
-        def finish(force=False):        # reassemble the last step's matrix on every rank (RCCL all-gather over xGMI)
-            if gather_end or force:
-                m.gather(0)
+        def reassemble():               # the one exchange of the path: RCCL all-gather of the row blocks over xGMI
+            m.gather(0)
     else:
         R = ref_inputs(wl)
         G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
@@ -234,8 +352,9 @@ def main():
         x_rx = t64(R["x_rx"])
         mout = None
         units_per_step = G * T * N
+        total_units_per_step = units_per_step * world
         alg_bytes = units_per_step * 16 + N * 16       # tof + land_x written per ray; alpha, z_f read once
-        kernel = "rtus_shoot_kernel"
+        kernel = "rtus_shoot_kernel<false>"
 
         def step(s):
             nonlocal mout
@@ -245,189 +364,204 @@ def main():
         def drain():
             pass
 
-        def finish(force=False):
+        def reassemble():
             pass
 
+    # ---- warm-up ----------------------------------------------------------------------------------
     for s in range(args.warmup):
         step(s)
     gather_error = None
-    try:
-        finish(force=gather_after)      # also warms the communicator up
-    except Exception as exc:            # the timed region needs no collective: keep measuring, report the failure
-        if not gather_after:
-            raise
-        gather_error = repr(exc)
-        print(f"[bench] warm-up all-gather failed: {gather_error}", file=sys.stderr)
+    if world > 1 and args.gather != "off":
+        try:
+            reassemble()                # also warms the communicator up
+        except Exception as exc:        # the timed region needs no collective: keep measuring, report the failure
+            if not gather_after:
+                raise
+            gather_error = repr(exc)
+            print(f"[bench] warm-up all-gather failed: {gather_error}", file=sys.stderr)
     drain()
     torch.cuda.synchronize()
 
-    # The K timed steps are K back-to-back launches on one stream.  Python + hipLaunchKernel cost
-    # ~10 us per call, comparable to the kernel itself on cfg2, so the K launches are captured once
-    # into a hipGraph and replayed (same kernels, same order, no per-launch host work).
-    graph = None
-    if args.graph == "on" and not gather:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                g = torch.cuda.CUDAGraph()
-                # thread_local: other threads (e.g. the RCCL watchdog at --gpus > 1) may keep issuing HIP calls
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    if args.streams > 1 and wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
-                        subs = [torch.cuda.Stream() for _ in range(args.streams)]     # fork ...
-                        for st in subs:
-                            st.wait_stream(side)
-                        for s in range(args.steps):
-                            with torch.cuda.stream(subs[s % args.streams]):             # step s -> stream / buffer s % S
-                                step(s)
-                        for st in subs:                                                   # ... and join
-                            side.wait_stream(st)
-                    else:
-                        for s in range(args.steps):
-                            step(s)
-            torch.cuda.current_stream().wait_stream(side)
-            # untimed replays: the first uploads the graph; then keep the GPU busy for PREWARM_MS so that the timed
-            # region starts at the sustained clock whatever K is (the clocks of an idle MI355X take a few ms of load
-            # to come up: a 200-step region measured cold reads ~10 % slower than a 2000-step one)
-            t_pre = time.perf_counter()
-            g.replay()
-            torch.cuda.synchronize()
-            one = max(time.perf_counter() - t_pre, 1e-5)
-            for _ in range(min(200, int(PREWARM_MS * 1e-3 / one))):
-                g.replay()
-            torch.cuda.synchronize()
-            graph = g
-        except Exception as exc:            # capture unsupported -> eager launches
-            print(f"[bench] hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()                      # same (current) stream the library launches on
-    if graph is not None:
-        graph.replay()
-    else:
-        for s in range(args.steps):
-            step(s)
-    ev1.record()
-    finish()
-    drain()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration over the timed region
+    # ---- timed region: K steps, barrier + synchronize on both sides, max over ranks -----------------
+    # Python + hipLaunchKernel cost ~10 us per call, so the K launches are captured once into a hipGraph and replayed
+    # (same kernels, same order, no per-launch host work).
+    timed = Timed(torch, step, args.steps, streams=args.streams if wl in PLANAR else 1,
+                  use_graph=args.graph == "on" and not gather_step)
+
+    def tail():
+        if gather_end:
+            reassemble()
+        drain()
+
+    dt, kern_ms = timed.run(barrier, tail)
+    dt = max_over_ranks(dt)
     reassembly_ms = None
     if gather_after and gather_error is None:         # the one exchange of the path, outside the solve loop
         try:
+            barrier()
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
-            finish(force=True)
+            reassemble()
             torch.cuda.synchronize()
             barrier()
-            reassembly_ms = (time.perf_counter() - t1) * 1e3
+            reassembly_ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
         except Exception as exc:
             gather_error = repr(exc)
             print(f"[bench] all-gather failed: {gather_error}", file=sys.stderr)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_units = units_per_step * world * args.steps
+    total_units = total_units_per_step * args.steps
     value = total_units / dt / 1e6
-
+    graph_on = timed.graph is not None
     out = {
         "metric": "Mrays/sec (elem x focal travel-time solves)", "value": round(value, 3), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32" if wl == "cfg4_lens_f32" else "f64", "data": "synthetic",
-        "config": {"workload": {
-            "cfg2_planar": "BASELINE configs[1]: 128-element array, 1 planar interface (z=20 mm, c=2330/1483 m/s), "
-                           "128x128 focal grid, fp64, per GPU",
-            "cfg3_planar": "BASELINE configs[2]: 256-element array, 2 planar interfaces, 512x512 focal grid, fp64, per GPU",
-            "cfg4_lens_f32": "BASELINE configs[3]: curved parametric interface (the reference lens), 128-element block of a "
-                             "1024-element array x 1024x1024 target grid, fp32, per GPU",
-            "cfg5_fmc": "BASELINE configs[4]: FMC tx/rx travel-time table, 3-layer medium + planar reflector, 256 tx rows x "
-                        "2048 rx, per GPU",
-            "ref_sweep": "reference sweep main_rt.py:464-501: 210 geometries x 905 rays forward trace + 65-element matcher",
-            "ref_scale": "reference geometry, 1024 tx x 8192 rays forward trace + 65-element matcher"}[wl],
+        "config": {
+            "workload": DESCR[wl] + ("" if world == 1 else
+                                     f"; {scaling}-scaled over {world} GPUs" +
+                                     (f" ({units_per_step // n_f if m is not None else 0} tx rows per GPU)" if m is not None else "")),
             "solves_per_step_per_gpu": units_per_step,
+            "solves_per_step_all_gpus": total_units_per_step,
             "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64)"}.get(
-                wl, "fp64 results (planar solver: max |dt| 3.3e-17 s vs the long-double oracle); its Newton PRE-iteration runs "
-                    "on the fp32 pipe, the result comes from an fp64 evaluation + Fermat expansion"
-                if wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc") else "fp64, reference-compatible arithmetic"),
-            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather else
+                wl, "fp64 results; the planar solver's Newton PRE-iteration runs on the fp32 pipe, the result comes from an "
+                    "fp64 evaluation + Fermat expansion (measured max |dt| vs the long-double oracle: see `accuracy`)"
+                if wl in PLANAR else "fp64, reference-compatible arithmetic"),
+            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather_step else
                                                        ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
-                                                       ", RCCL all-gather of the final matrix after the timed region" if gather_after else ""),
-            "launch": (f"hipGraph replay of K launches on {args.streams} stream(s)" if args.streams > 1 else "hipGraph replay of K launches") +
-                      f" (after ~{PREWARM_MS:.0f} ms of untimed replays: clock ramp)" if graph is not None
-                      else "eager launches",
+                                                       ", collective-free timed region; RCCL all-gather of the table timed right after" if gather_after else ""),
+            "launch": ((f"hipGraph replay of K launches on {args.streams} stream(s)" if args.streams > 1 else "hipGraph replay of K launches") +
+                       f" (after ~{PREWARM_MS:.0f} ms of untimed replays: clock ramp)") if graph_on else "eager launches",
         },
     }
     if reassembly_ms is not None:
-        shard_bytes = units_per_step * (4 if wl == "cfg4_lens_f32" else 8)
-        out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "ms": round(reassembly_ms, 4),
+        shard_bytes = m.per * n_f * word
+        per_step_s = dt / args.steps
+        out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL over xGMI)" if backend == "nccl" else f"all_gather_into_tensor ({backend})",
+                             "ms": round(reassembly_ms, 4),
                              "bytes_received_per_rank": shard_bytes * (world - 1),
-                             "GB_per_s_per_rank": round(shard_bytes * (world - 1) / (reassembly_ms * 1e-3) / 1e9, 2)}
+                             "GB_per_s_received_per_rank": round(shard_bytes * (world - 1) / (reassembly_ms * 1e-3) / 1e9, 2)}
+        out["value_with_reassembly"] = round(total_units / (dt + reassembly_ms * 1e-3) / 1e6, 3)     # K steps + ONE all-gather
+        out["value_reassembled_every_step"] = round(total_units_per_step / (per_step_s + reassembly_ms * 1e-3) / 1e6, 3)
     if gather_error is not None:
         out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "error": gather_error}
+    if world > 1:
+        out["multi_gpu_note"] = ("RCCL over xGMI first ran in the driver's scaling job (the build pool has one GPU per box); compare "
+                                 "this line with `extra.cfg4_lens_f32_full` (the same table on one GPU) of the N = 1 line" if wl == "cfg4_lens_f32"
+                                 else "per-GPU work fixed (weak scaling): no data-path collective")
+
     ach = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get(wl)
-        except Exception:
-            traffic = None
+    traffic_doc, traffic_src = load_profile_json("traffic_{tag}.json")
+    traffic = (traffic_doc or {}).get(wl)
     out["roofline"] = {
-        "bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "bound": "hbm", "binds": "valu_issue", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 5),
-        "note": "scalar root-find: 4-16 B of HBM traffic per solve, so the HBM fraction is small by "
-                "construction; the binding resource is VALU issue (see DESIGN.md, profiles/)",
+        "note": "HBM fraction as the contract asks (8 B written per fp64 solve, 4 B per fp32 solve); a scalar root-find moves "
+                "4-16 B per solve, so the binding resource is VALU issue, not HBM: see roofline_valu",
     }
+    valu_doc, valu_src = load_profile_json("valu_{tag}.json")
+    if valu_doc and wl in valu_doc:
+        v = dict(valu_doc[wl])
+        v["source"] = valu_src + " (rocprofv3 --pmc SQ_* pass of this workload; not collected in this run)"
+        if v.get("issue_cycles_per_wave_solve") and v.get("clock_ghz"):
+            # what the measured instruction mix would take at 100 % VALU issue efficiency vs what the launch took
+            simd = 1024.0
+            t_issue = (units_per_step / 64.0 / simd) * v["issue_cycles_per_wave_solve"] / (v["clock_ghz"] * 1e9)
+            v["issue_bound_ms"] = round(t_issue * 1e3, 5)
+            v["frac_of_issue_bound"] = round(t_issue * 1e3 / kern_ms, 4)
+        out["roofline_valu"] = v
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl)
-    if rank == 0 and world == 1 and not args.no_extra and wl == "cfg2_planar":
-        out["extra"] = extra_ref_path(dev_api, rtus, t64, torch)
+        gpu_table = m.local(0)[:n_e] if m is not None else None
+        out["cpu_baseline"], acc = cpu_baseline(wl, gpu_table, torch)
+        if acc is not None:
+            out["accuracy"] = acc
+            out["max_abs_dt_s"] = acc["max_abs_dt_s"]
+    if rank == 0 and world == 1 and not args.no_extra and wl == "cfg3_planar":
+        out["extra"] = extra_measurements(dev_api, dist_api, rtus, t64, torch, dev)
         if not args.no_cpu_baseline:
             out["extra"]["cpu_ref_path"] = cpu_ref_path()
+    if world > 1 and not args.no_extra and wl == "cfg4_lens_f32" and args.gather != "step":
+        fm = fmc_strong(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args)
+        if rank == 0:
+            out["extra"] = {"cfg5_fmc": fm}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(wl):
-    """Oracle-side CPU port timed on this host (bounded sample of the same workload)."""
+def fmc_strong(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args):
+    """BASELINE configs[4] on N GPUs: the 2048 x 2048 FMC table, tx rows sharded, collective-free solve + ONE all-gather."""
+    W = fmc_inputs(rank, world)
+    n_e, n_f = W["n_e"], W["n_f"]
+    m = dist_api.RowShardedMatrix(W["rows_total"], n_f, device=dev, slots=1)
+    plan = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=m.local(0)[:n_e])
+    for _ in range(5):
+        plan.run()
+    res = {"workload": DESCR["cfg5_fmc"], "rows_per_gpu": n_e}
+    try:
+        if args.gather != "off":
+            m.gather(0)
+        torch.cuda.synchronize()
+        K = max(20, min(args.steps, 200))
+        timed = Timed(torch, lambda s: plan.run(), K, use_graph=args.graph == "on")
+        dt, kern_ms = timed.run(barrier)
+        dt = max_over_ranks(dt)
+        tot = W["rows_total"] * n_f
+        res.update({"Mrays_per_s": round(tot * K / dt / 1e6, 1), "ms_per_step": round(dt / K * 1e3, 5), "steps": K,
+                    "avg_launch_ms": round(kern_ms, 5)})
+        if args.gather != "off":
+            barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m.gather(0)
+            torch.cuda.synchronize()
+            barrier()
+            g_ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
+            res.update({"reassembly_ms": round(g_ms, 4),
+                        "Mrays_per_s_reassembled_every_step": round(tot / (dt / K + g_ms * 1e-3) / 1e6, 1)})
+    except Exception as exc:
+        res["error"] = repr(exc)
+    return res
+
+
+# ------------------------------------------------------------------------------------ CPU legs (oracle = checker)
+def cpu_baseline(wl, gpu_table, torch):
+    """Oracle-side CPU port timed on this host + the GPU result checked against the long-double oracle on a seeded
+    sample (the only place bench.py touches oracle/).  -> (cpu_baseline dict, accuracy dict or None)"""
     from oracle import cport
     cores = cport.num_threads()
-    if wl in ("cfg2_planar", "cfg3_planar"):
-        W = planar_inputs(wl, 0, 1)
-        ne = min(W["n_e"], 128 if wl == "cfg2_planar" else 4)      # cfg2: the whole workload per call (2.1 M solves)
+    acc = None
+    if wl in ("cfg2_planar", "cfg3_planar", "cfg5_fmc"):
+        W = workload_inputs(wl, 0, 1)
+        ne = W["n_e"]
         cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:1], W["ze"][:1], W["xf"][:1024], W["zf"][:1024])
         reps, t0 = 0, time.perf_counter()
-        while True:
-            cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:ne], W["ze"][:ne], W["xf"], W["zf"])
+        while True:                                                    # the WHOLE workload per call
+            cport.tt_layers_newton(W["z_if"], W["c"], W["xe"], W["ze"], W["xf"], W["zf"])
             reps += 1
             if time.perf_counter() - t0 > 10.0:
                 break
         dt = time.perf_counter() - t0
-        v = reps * ne * W["n_f"] / dt / 1e6
-        return {"value": round(v, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} x ({ne} elements x {W['n_f']} focal points) of the same workload, "
+        base = {"value": round(reps * ne * W["n_f"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x the whole workload ({ne} elements x {W['n_f']} focal points), "
                           f"oracle/rt_oracle.c orc_tt_layers_newton (fp64 Newton, OpenMP)"}
-    if wl == "cfg5_fmc":
-        W = fmc_inputs(0, 1)
-        reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 10.0:
-            cport.tt_layers_newton(W["z_if"], W["c"], W["xe"][:64], W["ze"][:64], W["xf"], W["zf"])
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": round(reps * 64 * W["n_f"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} x (64 tx x 2048 rx) of the same table, orc_tt_layers_newton (fp64, OpenMP)"}
+        if gpu_table is not None:
+            rng = np.random.default_rng(20260)
+            re = np.sort(rng.choice(ne, size=min(16, ne), replace=False))
+            cf = np.sort(rng.choice(W["n_f"], size=min(8192, W["n_f"]), replace=False))
+            got = gpu_table[torch.as_tensor(re, device=gpu_table.device)][:, torch.as_tensor(cf, device=gpu_table.device)].cpu().numpy()
+            ref = cport.tt_layers(W["z_if"], W["c"], W["xe"][re], W["ze"][re], W["xf"][cf], W["zf"][cf])
+            same_nan = bool(np.array_equal(np.isnan(got), np.isnan(ref)))
+            d = np.abs(got - ref)
+            acc = {"max_abs_dt_s": float(np.nanmax(d)), "median_abs_dt_s": float(np.nanmedian(d)),
+                   "max_rel": float(np.nanmax(d / np.abs(ref))), "nan_masks_identical": same_nan,
+                   "sample": f"{re.size} seeded-random elements x {cf.size} seeded-random focal points of the timed workload's last step",
+                   "checker": "oracle/rt_oracle.c orc_tt_layers (long-double bisection; pinned to 50-digit values, parity unpinned "
+                              "by the reference: it has no planar interfaces)", "bar_s": 1e-9}
+        return base, acc
     if wl == "cfg4_lens_f32":
         W = lens_inputs(0, 1)
         import rtus
@@ -436,9 +570,21 @@ def cpu_baseline(wl):
             cport.tt_lens(W["xe"][:8], W["ze"][:8], W["xf"][:65536], W["zf"][:65536], -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
             reps += 1
         dt = time.perf_counter() - t0
-        return {"value": round(reps * 8 * 65536 / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        base = {"value": round(reps * 8 * 65536 / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                 "sample": f"{reps} x (8 elements x 65536 targets), orc_tt_lens (golden-section search in long double — a "
                           "checker, not a tuned CPU solver; OpenMP)"}
+        if gpu_table is not None:
+            rng = np.random.default_rng(20261)
+            re = np.sort(rng.choice(W["n_e"], size=8, replace=False))
+            cf = np.sort(rng.choice(W["n_f"], size=2048, replace=False))
+            got = gpu_table[torch.as_tensor(re, device=gpu_table.device)][:, torch.as_tensor(cf, device=gpu_table.device)].double().cpu().numpy()
+            ref, _ = cport.tt_lens(W["xe"][re], W["ze"][re], W["xf"][cf], W["zf"][cf], -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
+            d = np.abs(got - ref)
+            acc = {"max_abs_dt_s": float(np.nanmax(d)), "median_abs_dt_s": float(np.nanmedian(d)),
+                   "nan_masks_identical": bool(np.array_equal(np.isnan(got), np.isnan(ref))),
+                   "sample": "8 seeded-random elements x 2048 seeded-random targets", "checker": "orc_tt_lens (long double)",
+                   "bar_s": 1e-9}
+        return base, acc
     R = ref_inputs(wl)
     g = R["geoms"][:: max(1, R["geoms"].shape[0] // 16)][:16]
     xa = R["xa"][:8]
@@ -452,7 +598,7 @@ def cpu_baseline(wl):
     v = reps * g.shape[0] * xa.size * R["n"] / dt / 1e6
     return {"value": round(v, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x ({g.shape[0]} geometries x {xa.size} tx x {R['n']} rays) forward trace, "
-                      f"oracle/rt_oracle.c orc_shoot_batch (fp64, O(N) polyline scan per ray, OpenMP)"}
+                      f"oracle/rt_oracle.c orc_shoot_batch (fp64, O(N) polyline scan per ray, OpenMP)"}, None
 
 
 def cpu_ref_path():
@@ -477,6 +623,7 @@ def cpu_ref_path():
             "note": "forward trace at N = 905 (reference measured in SURVEY: 5.3 k rays/s on one core)"}
 
 
+# ------------------------------------------------------------------------------------ side measurements (N = 1)
 def _best_ms(torch, fn, k, blocks=5):
     """min over `blocks` of the mean time of k back-to-back calls (ms): a one-off host stall does not end up in the figure"""
     best = float("inf")
@@ -490,9 +637,25 @@ def _best_ms(torch, fn, k, blocks=5):
     return best
 
 
-def extra_ref_path(dev_api, rtus, t64, torch):
-    """Side measurement (not the headline): the reference-parity path on the same GPU."""
+def _event_ms(torch, fn, k, warm=3):
+    """mean HIP-event time of k back-to-back calls on the current stream (ms)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / k
+
+
+def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
+    """Side measurements (not the headline), one GPU: the other BASELINE configs and the reference-parity path."""
+    import ctypes as C
     res = {}
+    # --- the reference's own hot path: forward trace + matcher ------------------------------------------------
     for kind, fast in (("ref_sweep", False), ("ref_scale", False), ("ref_scale", True)):
         R = ref_inputs(kind)
         G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
@@ -508,48 +671,79 @@ def extra_ref_path(dev_api, rtus, t64, torch):
         for _ in range(3):
             one_pass()
         dt = _best_ms(torch, one_pass, 20 if kind == "ref_sweep" else 5) * 1e-3
-        res[kind + ("_fastmath" if fast else "")] = {"Mrays_per_s": round(G * T * N / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4),
-                     "rays_per_pass": G * T * N}
-    # the same planar kernel on BASELINE configs[2] (256 elements, 2 interfaces, 512 x 512 grid): a launch large
-    # enough (537 MB of results) that launch overhead and ramp no longer weigh on the HBM fraction
-    W = planar_inputs("cfg3_planar", 0, 1)
-    out3 = torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device="cuda")
-    plan3 = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=out3)
-    for _ in range(3):
-        plan3.run()
+        rays = G * T * N
+        entry = {"Mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4), "rays_per_pass": rays}
+        if kind == "ref_scale":
+            # roofline of the forward-trace kernel alone (HIP events around the trace, matcher excluded)
+            ms = _event_ms(torch, lambda: plan.run(*a), 5)
+            algb = rays * 16 + N * 16
+            entry["roofline"] = {"bound": "hbm", "binds": "valu_issue (fp64 transcendentals + crossing search)",
+                                 "kernel": f"rtus_shoot_kernel<{'true' if fast else 'false'}>", "avg_launch_ms": round(ms, 5),
+                                 "algorithmic_bytes_per_launch": algb, "achieved": round(algb / (ms * 1e-3) / 1e9, 2),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                 "G_rays_per_s_kernel_only": round(rays / (ms * 1e-3) / 1e9, 2)}
+        res[kind + ("_fastmath" if fast else "")] = entry
+    # --- BASELINE configs[1] (the small planar launch: 17 MB of results, one 4-wave round per SIMD) ---------------
+    W = planar_inputs("cfg2_planar", 0, 1)
+    out2 = torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device=dev)
+    plan2 = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=out2)
+    for _ in range(5):
+        plan2.run()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        plan3.run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms3 = e0.elapsed_time(e1) / 20
-    n3 = W["n_e"] * W["n_f"]
-    res["cfg3_planar"] = {"Mrays_per_s": round(n3 / ms3 / 1e3, 1), "ms_per_launch": round(ms3, 4), "solves_per_launch": n3,
-                          "hbm_frac": round(n3 * 8 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    del out3, plan3
-    # curved-lens two-point Fermat solves (BASELINE config 4 geometry: 1024 elements over the reference lens,
-    # 1024 x 256 target strip inside the insonified cone), fp64 and fp32
-    import ctypes as C
-    L = rtus.lib()
+    timed = Timed(torch, lambda s: plan2.run(), 500)
+    dt2, ms2 = timed.run(lambda: None)
+    n2 = W["n_e"] * W["n_f"]
+    res["cfg2_planar"] = {"Mrays_per_s": round(n2 * 500 / dt2 / 1e6, 1), "ms_per_launch": round(ms2, 5), "solves_per_launch": n2,
+                          "hbm_frac": round(n2 * 8 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "500 back-to-back launches replayed as a hipGraph; the 16.8 MB result fits the 256 MiB Infinity "
+                                  "Cache, so this 'HBM' fraction is fabric traffic, not DRAM traffic"}
+    del out2, plan2, timed
+    # --- BASELINE configs[3]: curved-lens two-point Fermat solves, fp32: the whole 1024 x 1024^2 table on one GPU (the
+    # N = 1 point of the strong-scaling series bench.py --gpus N runs) and the 128-row shard one of 8 GPUs solves ------
     lens = rtus.Params().lens()
-    d = rtus.Params().d
-    xe = (np.arange(1024) - 511.5) * 0.3e-4
-    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 1024), np.linspace(0.03, 0.07, 256))
-    for name, dt, fn in (("lens_fermat_f64", torch.float64, L.rtus_tt_lens_dev), ("lens_fermat_f32", torch.float32, L.rtus_tt_lens_f32_dev)):
-        mk = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda").to(dt).contiguous()
-        txe, tze, txf, tzf = mk(xe), mk(np.full(1024, d)), mk(xs.ravel()), mk(zs.ravel())
-        out = torch.empty((1024, txf.numel()), dtype=dt, device="cuda")
-        run = lambda: fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, txe.data_ptr(), tze.data_ptr(), 1024,
-                         txf.data_ptr(), tzf.data_ptr(), txf.numel(), out.data_ptr(), None,
-                         torch.cuda.current_stream().cuda_stream)
-        for _ in range(2):
-            assert run() == 0
-        dtm = _best_ms(torch, run, 3, blocks=3) * 1e-3
-        n = 1024 * txf.numel()
-        res[name] = {"Mrays_per_s": round(n / dtm / 1e6, 1), "ms_per_pass": round(dtm * 1e3, 3), "solves_per_pass": n}
-    # root-finding pulse-echo solve: the reference sweep's 210 geometries x 65 elements
+    L = rtus.lib()
+    for name, rows in (("cfg4_lens_f32_full", 1024), ("cfg4_lens_f32_shard128", 128)):
+        Wl = lens_inputs(0, 1, n_rows=rows)
+        mk = lambda a_: torch.as_tensor(np.ascontiguousarray(a_, dtype=np.float32), device=dev)
+        txe, tze, txf, tzf = mk(Wl["xe"]), mk(Wl["ze"]), mk(Wl["xf"]), mk(Wl["zf"])
+        outl = torch.empty((rows, Wl["n_f"]), dtype=torch.float32, device=dev)
+        run = lambda: L.rtus_tt_lens_f32_dev(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, txe.data_ptr(), tze.data_ptr(), rows,
+                                             txf.data_ptr(), tzf.data_ptr(), Wl["n_f"], outl.data_ptr(), None,
+                                             torch.cuda.current_stream().cuda_stream)
+        assert run() == 0
+        ms = _event_ms(torch, run, 10 if rows == 1024 else 40)
+        n = rows * Wl["n_f"]
+        res[name] = {"Mrays_per_s": round(n / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "solves_per_launch": n,
+                     "hbm_frac": round(n * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del outl
+    # fp64 instantiation of the same kernel on a 1024 x (1024 x 256) strip
+    Wl = lens_inputs(0, 1)
+    mk = lambda a_: torch.as_tensor(np.ascontiguousarray(a_, dtype=np.float64), device=dev)
+    nf64 = 1024 * 256
+    txe, tze, txf, tzf = mk(Wl["xe"]), mk(Wl["ze"]), mk(Wl["xf"][:nf64]), mk(Wl["zf"][:nf64])
+    outl = torch.empty((1024, nf64), dtype=torch.float64, device=dev)
+    run = lambda: L.rtus_tt_lens_dev(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, txe.data_ptr(), tze.data_ptr(), 1024,
+                                     txf.data_ptr(), tzf.data_ptr(), nf64, outl.data_ptr(), None,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert run() == 0
+    ms = _event_ms(torch, run, 5)
+    res["lens_fermat_f64"] = {"Mrays_per_s": round(1024 * nf64 / ms / 1e3, 1), "ms_per_launch": round(ms, 4),
+                              "solves_per_launch": 1024 * nf64}
+    del outl
+    # --- BASELINE configs[4]: the whole 2048 x 2048 FMC table on one GPU --------------------------------------------
+    Wf = fmc_inputs(0, 1)
+    outf = torch.empty((Wf["n_e"], Wf["n_f"]), dtype=torch.float64, device=dev)
+    planf = dev_api.LayersPlan(Wf["z_if"], Wf["c"], t64(Wf["xe"]), t64(Wf["ze"]), t64(Wf["xf"]), t64(Wf["zf"]), out=outf)
+    for _ in range(5):
+        planf.run()
+    torch.cuda.synchronize()
+    timed = Timed(torch, lambda s: planf.run(), 200)
+    dtf, msf = timed.run(lambda: None)
+    nfm = Wf["n_e"] * Wf["n_f"]
+    res["cfg5_fmc_full"] = {"Mrays_per_s": round(nfm * 200 / dtf / 1e6, 1), "ms_per_launch": round(msf, 5), "solves_per_launch": nfm,
+                            "hbm_frac": round(nfm * 8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del outf, planf, timed
+    # --- root-finding pulse-echo solve: the reference sweep's 210 geometries x 65 elements --------------------------
     R = ref_inputs("ref_sweep")
     sol = [None]
 
@@ -559,8 +753,39 @@ def extra_ref_path(dev_api, rtus, t64, torch):
     dtm = _best_ms(torch, one_solve, 3, blocks=3) * 1e-3
     tt = sol[0]
     res["solve_sweep_host_api"] = {"ms_per_pass": round(dtm * 1e3, 3), "elements": int(tt.size),
-                                   "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe + alloc"}
+                                   "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe"}
+    # --- the reference's calling pattern: 210 sequential shoot_rays(N = 905) calls + matcher (main_rt.py:464-504) ------
+    res["sweep_like_main_rt"] = sweep_like_reference(rtus)
     return res
+
+
+def sweep_like_reference(rtus):
+    """The reference's own driver loop, call for call (main_rt.py:464-504): 210 x shoot_rays(x_a[32], z_a[32], zf, alpha)
+    through the host-buffer API (NumPy in, dict of 8 NumPy arrays out) + the 65-element matcher per geometry.
+    The reference takes 141 s for this on one Xeon core."""
+    d = rtus.Params().d
+    n = 905
+    x_a = rtus.reference_elements()
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, d)
+    geoms = [(r * 1e-2, o * 1e-3) for r in range(1, 11) for o in range(-10, 11)]
+    rtus.shoot_rays(x_a[32], d, zf, alpha, params=rtus.Params(r_outer=0.05, pipe_offset=0.0))      # warm
+    t0 = time.perf_counter()
+    hits = 0
+    for r_o, off in geoms:
+        p = rtus.Params(r_outer=r_o, pipe_offset=off)
+        res = rtus.shoot_rays(x_a[32], d, zf, alpha, plot=False, params=p)
+        b = rtus.shoot_batch([x_a[32]], [d], zf, alpha, params=p, want=("tof", "land_x"))
+        hit, tof, _ = rtus.match_elements(b["land_x"][0, 0], b["tof"][0, 0], x_a, atol=1e-6)
+        hits += int(hit.sum())
+    wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for r_o, off in geoms[:50]:
+        rtus.shoot_rays(x_a[32], d, zf, alpha, plot=False, params=rtus.Params(r_outer=r_o, pipe_offset=off))
+    per_call = (time.perf_counter() - t1) / 50
+    return {"wall_s": round(wall, 4), "calls": len(geoms), "hits": hits, "shoot_rays_us_per_call": round(per_call * 1e6, 1),
+            "reference_wall_s": 141.0, "note": "210 sequential shoot_rays + shoot_batch + match_elements calls through the "
+            "host-buffer API (PCIe + launch latency per call); reference: 141 s on one Xeon core (SURVEY section 6)"}
 
 
 if __name__ == "__main__":
