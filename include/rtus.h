@@ -183,7 +183,12 @@ int rtus_ray_hits(const double *land_x, int n_batch, int n_rays, const double *x
  *   xf,zf [n_f]    targets (focal points), zf > ze; the path stops in whichever layer holds zf
  *   tt   [n_e][n_f] travel times [s]; NaN where zf <= ze
  *   iters [n_e][n_f] uint8 nullable: Newton iterations used (diagnostic)
- * rtus_tt_layers_f32 computes in fp32 (BASELINE config 4's dtype), same layout with floats.
+ *
+ * rtus_tt_layers_batch_dev: n_batch independent problems of one shape and one medium in ONE launch — several
+ * apertures and / or several target sets, the way the reference's driver sweeps 210 geometries (main_rt.py:464-467).
+ * Problem b reads d_xe/d_ze + b*e_stride, d_xf/d_zf + b*f_stride and writes d_tt + b*t_stride (strides in doubles;
+ * a stride of 0 shares that input between all problems; t_stride >= n_e*n_f).  A small problem (BASELINE config 2 is a
+ * single round of 4 waves per SIMD) no longer pays a launch ramp and drain of its own.
  * ---------------------------------------------------------------------------------------- */
 #define RTUS_MAX_LAYERS 8
 
@@ -191,6 +196,11 @@ int rtus_tt_layers_dev(const double *z_if, const double *c, int n_if,
                        const double *d_xe, const double *d_ze, int n_e,
                        const double *d_xf, const double *d_zf, int n_f,
                        double *d_tt, uint8_t *d_iters, void *stream);
+
+int rtus_tt_layers_batch_dev(const double *z_if, const double *c, int n_if,
+                             const double *d_xe, const double *d_ze, int n_e, long long e_stride,
+                             const double *d_xf, const double *d_zf, int n_f, long long f_stride,
+                             double *d_tt, long long t_stride, int n_batch, void *stream);
 
 int rtus_tt_layers(const double *z_if, const double *c, int n_if,
                    const double *xe, const double *ze, int n_e,

@@ -77,6 +77,9 @@ def lib():
     L.rtus_ray_hits.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, ip]
     L.rtus_tt_layers_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, vp]
     L.rtus_tt_layers.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, ip]
+    L.rtus_tt_layers_batch_dev.argtypes = [dp, dp, ip, dp, dp, ip, C.c_longlong, dp, dp, ip, C.c_longlong, dp,
+                                           C.c_longlong, ip, vp]
+    L.rtus_tt_layers_batch_dev.restype = ip
     L.rtus_tt_lens_dev.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, vp]
     L.rtus_tt_lens.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, ip]
     L.rtus_tt_lens_f32_dev.argtypes = L.rtus_tt_lens_dev.argtypes
@@ -104,6 +107,6 @@ def check(status, what):
 
 EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count",
            "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
-           "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers",
+           "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_tt_layers_batch_dev",
            "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",
            "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve")

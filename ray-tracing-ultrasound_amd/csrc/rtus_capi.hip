@@ -23,6 +23,9 @@ hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batc
 hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
                                  double* tt, uint8_t* iters, hipStream_t s);
+hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int n_if, const double* xe, const double* ze,
+                                       int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
+                                       long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s);
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
@@ -354,6 +357,20 @@ int rtus_tt_layers_dev(const double* z_if, const double* c, int n_if, const doub
     if (st) return st;
     HIP_TRY(rtus_launch_tt_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters,
                                   (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tt_layers_batch_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze,
+                             int n_e, long long e_stride, const double* d_xf, const double* d_zf, int n_f,
+                             long long f_stride, double* d_tt, long long t_stride, int n_batch, void* stream)
+{
+    int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
+    if (st) return st;
+    if (n_batch <= 0 || e_stride < 0 || f_stride < 0) return RTUS_ERR_INVALID_ARG;
+    if (n_batch > 1 && t_stride < (long long)n_e * n_f) return RTUS_ERR_INVALID_ARG;   // outputs of two problems would overlap
+    if (n_batch > 65535) return RTUS_ERR_UNSUPPORTED;                                   // grid.z
+    HIP_TRY(rtus_launch_tt_layers_batch(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt,
+                                        t_stride, n_batch, (hipStream_t)stream));
     return RTUS_OK;
 }
 

@@ -12,20 +12,22 @@
 // q stays finite even at grazing incidence (unlike p -> 1/cm).  Convergence is tested per wave
 // with a ballot so a wave leaves the loop as soon as all 64 lanes are done.
 //
-// Cost model (measured, scripts/ubench_fp64.hip): an fp64 fma/mul/add wave-op costs ~2 ns of SIMD
-// time, v_rsq_f64 / v_rcp_f64 ~6.8 ns (seed accuracy 5e-8), IEEE sqrt ~36 ns, IEEE divide ~25 ns.
-// So the Newton iteration runs entirely on the fp32 pipe (v_fma_f32 ~1 ns, v_rsq_f32 / v_rcp_f32
-// ~3.4 ns): it only has to bring q within 3e-4 of the root — Newton needs neither an exact Jacobian nor
-// an exact residual for that — and the fp64 result is produced afterwards; no IEEE sqrt/divide anywhere.
+// Cost model (measured on gfx950, scripts/ubench_issue*.hip -> profiles/r02_ubench_issue.txt; cycles per
+// wave-instruction per SIMD at 8 waves/SIMD): fp32 fma / mul / add / mov with VGPR or inline-constant operands 2.3;
+// the same with an SGPR operand 4.2; every fp64 op, v_cvt, v_max/v_min, v_cmp, v_readlane, v_bfi 4.2; v_rsq_f32 /
+// v_rcp_f32 8.2; v_pk_fma_f32 4.2 (packed fp32 buys no issue slots on this part); IEEE fp64 sqrt ~85, divide ~60.
+// So the Newton iteration runs entirely on the fp32 pipe with per-lane (VGPR) tables: it only has to bring q within
+// 3e-4 of the root — Newton needs neither an exact Jacobian nor an exact residual for that — and the fp64 result is
+// produced afterwards; no IEEE sqrt/divide anywhere.
 //   * a lane stops when the step it would take is |dq| <= 3e-4 q; it does NOT take that step, so the
-//     seeds of its last evaluation belong to its q and are refined (one cubic step, ~1 ulp) instead
+//     seeds of its last evaluation belong to its q and are refined (one Newton step in fp64, 1.5 d^2) instead
 //     of being recomputed;
 //   * T at the exact root follows from the Fermat expansion in the residual dXr = X - X(q):
-//     T = T(q) + p dXr + (1/2)(dp/dX) dXr^2,  p = dT/dX = sin(theta)/c  — error O(dXr^3): measured max 3.3e-17 s
-//     (median 3e-21 s) against the long-double oracle on BASELINE config 2.
+//     T = T(q) + p dXr + (1/2)(dp/dX) dXr^2,  p = dT/dX = sin(theta)/c  — error O(dXr^3): measured max 3.4e-18 s
+//     (median 3e-20 s) against the long-double oracle on BASELINE config 3.
 //
-// Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced,
-// the element coordinates and all layer constants are wave-uniform (SGPRs).
+// Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced; the
+// per-element data of a workgroup (coordinates, extrapolation weights) sits in LDS and is broadcast to the lanes.
 #include "rtus_device.h"
 
 struct LayerArgs {
@@ -40,251 +42,319 @@ struct LayerArgs {
     double* __restrict__ tt;
     uint8_t* __restrict__ iters;
     int n_e, n_f;
-    int eb;                            // elements per workgroup
+    int eb;                            // elements per workgroup (<= 64)
+    // batched entry (rtus_tt_layers_batch): problem b = blockIdx.z uses elements / targets / output shifted by these
+    long long e_stride, f_stride, t_stride;   // in elements of the respective arrays (0: shared by all problems)
 };
 
 // Refine an fp32-pipe seed y ~ a^(-1/2) (relative error d <= ~1.5e-7: v_rsq_f32 plus the rounding of its argument)
 // with one Newton step in fp64: e = 1 - a y^2,  y <- y (1 + e/2)  -> error 1.5 d^2 <= 4e-14.  On the travel time
-// that is < 2e-18 s — an order below the O(dX^3) remainder of the expansion it feeds — and fp64 instructions are what
-// this kernel is short of (half the fp32 issue rate): the cubic step used before cost one more per square root.
+// that is < 2e-18 s — an order below the O(dX^3) remainder of the expansion it feeds.
 __device__ __forceinline__ double rsqrt_refine(double a, double y)
 {
     const double e = fma(-a * y, y, 1.0);
     return fma(y * e, 0.5, y);
 }
 
-// Seed for a^(-1/2), a >= 1: the fp32 pipe (cvt + v_rsq_f32 + cvt, ~3.6 ns) is cheaper than
-// v_rsq_f64 (~6.8 ns) at about the same accuracy (1e-7).  (a > 3e38 would need q > 1e19: not a ray.)
-__device__ __forceinline__ double rsqrt_seed(double a)
+// One element's record in LDS: every lane of the workgroup reads the same address (broadcast, no VALU slot —
+// a v_readlane costs 4.2 cycles and leaves its value in an SGPR, which halves the rate of every fp32 op reading it).
+struct __attribute__((aligned(16))) ElemRec {
+    float w1, w2, w3, w4;   // extrapolation weights on the signed solutions of the four previous elements
+    double xe;
+    int info;               // bits 0-2: previous elements usable as history (0..4); bit 3: depth differs from the previous
+                            // element's (layer set-up needed); bits 8..: length of the run of 4-history elements starting here
+    int pad;
+};
+
+// Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
+// traversed layer (there k = 0 and w = (1 + k q^2)^(-1/2) = 1 exactly: slot 0 needs no rsqrt anywhere).
+template <int NL>
+struct Lane {
+    double hr0, hc0, hr[NL], kk[NL], hc[NL], inv_cm;       // slots 1 .. NL-1 of the arrays are used
+    float hr0f, hrf[NL], kkf[NL], rs0f, rhmf, asymf;       // fp32 copies for the Newton loop, cold-start bounds
+    float tau;                                             // relative step below which a lane stops (+inf: target not below the element)
+    float rS3;                                             // 1 / X'(q) of the latest evaluation
+};
+
+template <int NL>
+__device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, double zf, Lane<NL>& L)
 {
-    return (double)__builtin_amdgcn_rsqf((float)a);
-}
-// Seed for 1/a through the fp32 pipe (1e-7); a must be within float range (sums of h r w^3: it is).
-__device__ __forceinline__ double rcp_seed(double a)
-{
-    return (double)__builtin_amdgcn_rcpf((float)a);
+    const bool valid = zf > ze;
+    L.tau = valid ? 3e-4f : INFINITY;
+    // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
+    double cm = 0.0, h[NL], hr_l[NL], hc_l[NL], kk_l[NL];   // _l: in layer order
+    L.inv_cm = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const double top = (i == 0) ? ze : fmax(a.z_if[i - 1], ze);
+        const double bot = (i < NL - 1) ? fmin(a.z_if[i], zf) : zf;
+        h[i] = fmax(bot - top, 0.0);
+        const bool faster = h[i] > 0.0 && a.c[i] > cm;
+        cm = faster ? a.c[i] : cm;
+        L.inv_cm = faster ? a.inv_c[i] : L.inv_cm;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
+        const double r = fastest ? 1.0 : a.c[i] * L.inv_cm;
+        hr_l[i] = h[i] * r;
+        hc_l[i] = h[i] * a.inv_c[i];
+        kk_l[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
+    }
+    // slot 0 <-> the first layer whose speed is cm (per lane: which layers a path crosses depends on zf)
+    int jf = 0;
+#pragma unroll
+    for (int i = NL - 1; i >= 1; --i) jf = (a.c[i] == cm) ? i : jf;
+    jf = (a.c[0] == cm) ? 0 : jf;
+    L.hr0 = hr_l[0]; L.hc0 = hc_l[0];
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        const bool sw = i == jf;
+        L.hr0 = sw ? hr_l[i] : L.hr0;        L.hc0 = sw ? hc_l[i] : L.hc0;
+        L.hr[i] = sw ? hr_l[0] : hr_l[i];    L.hc[i] = sw ? hc_l[0] : hc_l[i];    L.kk[i] = sw ? kk_l[0] : kk_l[i];
+    }
+#pragma unroll
+    for (int i = 1; i < NL; ++i) { L.hrf[i] = (float)L.hr[i]; L.kkf[i] = (float)L.kk[i]; }
+    L.hr0f = (float)L.hr0;
+    // the two lower bounds of a cold start, formed on the fp32 pipe (they are only a starting guess):
+    // X <= s0 q with s0 = X'(0), and X <= hm q + asym — the fastest layer(s) (k = 0) contribute the linear term
+    // h q, every slower layer saturates at h r / sqrt(k).  Shaved so that fp32 rounding keeps them lower bounds.
+    float s0f = L.hr0f, hmf = L.hr0f, asf = 0.0f;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        const bool lin = L.kkf[i] == 0.0f;
+        s0f += L.hrf[i];
+        hmf += lin ? L.hrf[i] : 0.0f;
+        asf += lin ? 0.0f : L.hrf[i] * __builtin_amdgcn_rsqf(L.kkf[i]);
+    }
+    L.rs0f = __builtin_amdgcn_rcpf(s0f) * (1.0f - 4e-6f);
+    L.rhmf = __builtin_amdgcn_rcpf(hmf) * (1.0f - 4e-6f);
+    L.asymf = asf * (1.0f + 4e-6f);
+    L.hc0 = valid ? L.hc0 : NAN;                    // target not below the element: T = NaN falls out of the sums
+    L.rS3 = 0.0f;
 }
 
-// v_readlane of a double held one-per-lane (the lane index is wave-uniform: an SGPR)
-__device__ __forceinline__ double readlane_f64(double v, int l)
+// One (element, target) solve.  h1 .. h4: signed solutions qs = sign(xf - xe) q of the four previous elements
+// (h1 the latest); the new one is returned.  FAST: the element has four usable predecessors — the cubic extrapolation
+// is within 3e-4 of the root for all but ~1e-4 of the solves, so the lower-bound clamp is only formed when a lane
+// of the wave asks for a second Newton evaluation.
+template <int NL, bool ITERS, bool FAST>
+__device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, const ElemRec& R, int hist, double xf,
+                                            float h1, float h2, float h3, float h4, bool live, size_t out_index)
 {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ float readlane_f32(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    const double dxs = xf - R.xe;
+    const double X = fabs(dxs);
+    // ---- Newton iteration in fp32 -----------------------------------------------------------
+    // The loop only has to bring q within 3e-4 of the root (the fp64 expansion below removes the
+    // rest to third order), so it runs on the fp32 pipe: half the issue cost of fp64 and native
+    // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise three orders below
+    // the stopping threshold.  Lanes whose target is not below the element carry garbage
+    // through the arithmetic (never a step: tau = +inf) and get NaN at the store.
+    const float Xf = (float)X;
+    float y[NL], dq = 0.0f;                                 // dq: the (small, untaken) Newton step of the last evaluation
+    int it = 0;
+    // one evaluation of X(q), X'(q) on the fp32 pipe -> Newton step dq; y[] = the rsqrt seeds of this q
+    auto eval = [&](float qq) {
+        const float q2 = qq * qq;
+        float S1 = L.hr0f, S3 = L.hr0f;                     // slot 0: k = 0, y = 1
+#pragma unroll
+        for (int i = 1; i < NL; ++i) {
+            y[i] = __builtin_amdgcn_rsqf(fmaf(L.kkf[i], q2, 1.0f));
+            const float hw = L.hrf[i] * y[i];
+            S1 += hw;
+            S3 = fmaf(hw, y[i] * y[i], S3);
+        }
+        L.rS3 = __builtin_amdgcn_rcpf(S3);
+        dq = fmaf(-S1, qq, Xf) * L.rS3;
+    };
+    // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
+    auto lower_bound = [&]() { return fmaxf(fmaxf(Xf * L.rs0f, (Xf - L.asymf) * L.rhmf), 0.0f); };
+    // Newton from q, every iterate clamped to lb.  A lane is done when the step it WOULD take is small; it does not
+    // take it, so y[] stays the y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
+    auto newton = [&](float& q, float lb) {
+        for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
+            eval(q);
+            const bool big = fabsf(dq) > L.tau * q;         // tau = +inf on lanes without a path: never a step
+            if (!__builtin_amdgcn_ballot_w64(big)) break;
+            q = big ? fmaxf(q + dq, lb) : q;
+            if (ITERS) it += big ? 1 : 0;
+        }
+    };
+    float q;
+    if (FAST) {
+        // the cubic extrapolation is nearly always within tau of the root: one evaluation, no clamp, no select
+        q = fabsf(fmaf(R.w1, h1, fmaf(R.w2, h2, fmaf(R.w3, h3, R.w4 * h4))));
+        eval(q);
+        const bool big = fabsf(dq) > L.tau * q;
+        if (__builtin_amdgcn_ballot_w64(big)) {             // rare (wave-uniform): some lane wants a second evaluation
+            asm volatile("" : "+v"(q));                     // keeps this block a branch (nothing of it is speculated)
+            const float lb = lower_bound();
+            q = big ? fmaxf(q + dq, lb) : q;
+            if (ITERS) it += big ? 1 : 0;
+            newton(q, lb);
+        }
+    } else {
+        const float lb = lower_bound();
+        q = lb;
+        if (hist > 0)                                       // wave-uniform; unused weights are 0
+            q = fmaxf(fabsf(fmaf(R.w1, h1, fmaf(R.w2, h2, fmaf(R.w3, h3, R.w4 * h4)))), lb);
+        newton(q, lb);
+    }
+    // ---- fp64: accurate T at q + the Fermat expansion in the residual dXr = X - X(q) ----------
+    // T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
+    // p = sin(theta)/cm = q u / cm,  dp/dX = u^3 / (cm X'(q)),  u = 1/sqrt(1+q^2).
+    const double qd = (double)q;
+    const double q2 = qd * qd;
+    const double a1 = 1.0 + q2;
+    const float us = __builtin_amdgcn_rsqf(fmaf(q, q, 1.0f));   // u to 1e-7 on the fp32 pipe: seed + 2nd-order term
+    const double u = rsqrt_refine(a1, (double)us);
+    double A1 = L.hr0, ST = L.hc0;                          // slot 0: w = 1
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        const double w = rsqrt_refine(fma(L.kk[i], q2, 1.0), (double)y[i]);
+        A1 = fma(L.hr[i], w, A1);
+        ST = fma(L.hc[i], w, ST);
+    }
+    const double dXr = fma(-A1, qd, X);
+    // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
+    // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
+    const float s2 = (0.5f * us) * (us * L.rS3);
+    const double T = u * fma(L.inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
+    if (live) {
+        a.tt[out_index] = T;
+        if (ITERS) a.iters[out_index] = (uint8_t)it;
+    }
+    // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
+    const float qroot = q + dq;
+    return __int_as_float((__float_as_int(qroot) & 0x7fffffff) | (__double2hiint(dxs) & 0x80000000));
 }
 
 // A workgroup = 256 focal points x `eb` consecutive elements (loop).  Besides re-using the layer
 // set-up while ze repeats, the loop gives each lane a CONTINUATION PREDICTOR: the signed solution
-// qs = sign(xf - xe) q is a smooth function of the element position, so the three previous
-// solutions extrapolate the next one to ~1e-3..1e-4 and Newton needs ~1.5 evaluations instead of ~4.5.
-// The extrapolation weights depend on the element positions only: lane l works them out once for element
-// e0 + l (Lagrange form) and the loop fetches them with v_readlane — three fp32 FMAs per solve.
-// The predictor is only a guess: every iterate is clamped to the rigorous lower bound of the root,
+// qs = sign(xf - xe) q is a smooth function of the element position, so the four previous
+// solutions extrapolate the next one (cubic Lagrange form on the actual element positions) to ~1e-5 .. 1e-7
+// and Newton needs one evaluation instead of ~4.5.  The weights depend on the element positions only: thread t of
+// the workgroup works them out once for element e0 + t and parks them in LDS.
+// The predictor is only a guess: iterates are clamped to the rigorous lower bound of the root,
 // from which Newton is monotone, so convergence never depends on the elements being evenly spaced.
 template <int NL, bool ITERS>   // NL = number of layers the medium has (n_if + 1)
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
 {
+    __shared__ ElemRec rec[64];
+    // batched launch: problem blockIdx.z
+    a.xe += (size_t)blockIdx.z * a.e_stride; a.ze += (size_t)blockIdx.z * a.e_stride;
+    a.xf += (size_t)blockIdx.z * a.f_stride; a.zf += (size_t)blockIdx.z * a.f_stride;
+    a.tt += (size_t)blockIdx.z * a.t_stride;
+    if (ITERS) a.iters += (size_t)blockIdx.z * a.t_stride;
+
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const double xf = a.xf[f], zf = a.zf[f];
     const int e0 = blockIdx.y * a.eb;
-    const int e1 = min(e0 + a.eb, a.n_e);
-    // the workgroup's element coordinates: ONE vector load per wave (lane l holds element e0+l, eb <= 64),
-    // then v_readlane per loop trip — no memory latency inside the element loop.
-    const int lane = threadIdx.x & 63;
-    const int el = min(e0 + lane, a.n_e - 1);
-    const double xe_v = a.xe[el], ze_v = a.ze[el];
-    // predictor set-up for element e0 + lane: how many predecessors inside this block share its depth
-    // (the history restarts when ze changes), and the extrapolation weights on their solutions.
-    float w1_v = 0.0f, w2_v = 0.0f, w3_v = 0.0f;
-    int info_v;                                            // bits 0-1: 0 no guess, 1 proportional, 2 weights; bit 2: new ze
-    {
-        const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0);
-        const double x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3];
-        const double z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3];     // all loads issued together: one round trip
-        // '&', not '&&': keeps the compiler from sinking a load behind the previous comparison
-        const bool s1 = (lane >= 1) & (z1 == ze_v), s2 = s1 & (lane >= 2) & (z2 == ze_v), s3 = s2 & (lane >= 3) & (z3 == ze_v);
-        const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
-        // branch-free on purpose (selects): a branch here lets the compiler sink the x loads behind it,
-        // which costs the prologue a second memory round trip
-        // three differences in fp64, the other three from them on the fp32 pipe (t2 = xe - x2 = t1 + d12, ...)
-        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), t1 = (float)(xe_v - x1);
-        const float d23 = d13 - d12, t2 = t1 + d12, t3 = t1 + d13;
-        const bool lin = (hist >= 2) & (x1 != x2);                       // else: duplicate positions, no slope
-        const bool quad = lin & (hist >= 3) & (x3 != x1) & (x3 != x2);   // quadratic through the last three solutions
-        const float r12 = __builtin_amdgcn_rcpf(d12);
-        const float q1 = t2 * t3 * __builtin_amdgcn_rcpf(d12 * d13);
-        const float q2 = -t1 * t3 * __builtin_amdgcn_rcpf(d12 * d23);
-        const float q3 = t1 * t2 * __builtin_amdgcn_rcpf(d13 * d23);
-        w1_v = quad ? q1 : (lin ? t2 * r12 : 0.0f);                      // linear through the last two otherwise
-        w2_v = quad ? q2 : (lin ? -t1 * r12 : 0.0f);
-        w3_v = quad ? q3 : 0.0f;
-        const int mode = lin ? 2 : (hist >= 1 ? 1 : 0);
-        info_v = mode | (hist == 0 ? 4 : 0);
-    }
+    const int ne = min(a.eb, a.n_e - e0);                   // elements of this workgroup (<= 64)
 
-    // Per-lane layer table, PERMUTED so that slot 0 is the lane's fastest traversed layer: there k = 0 and
-    // w = (1 + k q^2)^(-1/2) = 1 exactly, so slot 0 needs no rsqrt anywhere (hr0, hc0 enter the sums directly).
-    double hr0 = 0.0, hc0 = 0.0, hr[NL], kk[NL], hc[NL];             // slots 1 .. NL-1 of the arrays are used
-    double inv_cm = 0.0;
-    float hr0f = 0.0f, hrf[NL], kkf[NL], rs0f = 0.0f, rhmf = 0.0f, asymf = 0.0f;   // fp32 copies for the Newton loop
-    float qs1 = 0.0f, qs2 = 0.0f, qs3 = 0.0f;             // signed solutions of the three previous elements
-    bool valid = false;
-    float rS3 = 0.0f;                                      // 1 / X'(q) of the latest Newton evaluation (kept across elements)
-    float tau = INFINITY;                                  // relative step below which a lane stops iterating
-    for (int e = e0; e < e1; ++e) {                         // wave-uniform loop
-        const int li = e - e0;
-        const int info = __builtin_amdgcn_readlane(info_v, li);
-        const double xe = readlane_f64(xe_v, li);
-        if (info & 4) {                                     // wave-uniform: redo the layer set-up only when ze changes
-            const double ze = readlane_f64(ze_v, li);
-            valid = zf > ze;
-            tau = valid ? 3e-4f : INFINITY;
-            qs1 = qs2 = qs3 = 0.0f;                         // a lane may carry NaN history from a depth at which its target was
-                                                            // not below the element; the linear predictor multiplies qs3 by 0
-            // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
-            double cm = 0.0, h[NL], hr_l[NL], hc_l[NL], kk_l[NL];   // _l: in layer order
-            inv_cm = 0.0;
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const double top = (i == 0) ? ze : fmax(a.z_if[i - 1], ze);
-                const double bot = (i < NL - 1) ? fmin(a.z_if[i], zf) : zf;
-                h[i] = fmax(bot - top, 0.0);
-                const bool faster = h[i] > 0.0 && a.c[i] > cm;
-                cm = faster ? a.c[i] : cm;
-                inv_cm = faster ? a.inv_c[i] : inv_cm;
-            }
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const bool fastest = a.c[i] == cm;          // exact: cm IS one of the c[i]
-                const double r = fastest ? 1.0 : a.c[i] * inv_cm;
-                hr_l[i] = h[i] * r;
-                hc_l[i] = h[i] * a.inv_c[i];
-                kk_l[i] = fastest ? 0.0 : fmax(fma(-r, r, 1.0), 0.0);
-            }
-            // slot 0 <-> the first layer whose speed is cm (per lane: which layers a path crosses depends on zf)
-            int jf = 0;
-#pragma unroll
-            for (int i = NL - 1; i >= 1; --i) jf = (a.c[i] == cm) ? i : jf;
-            jf = (a.c[0] == cm) ? 0 : jf;
-            hr0 = hr_l[0]; hc0 = hc_l[0];
-#pragma unroll
-            for (int i = 1; i < NL; ++i) {
-                const bool sw = i == jf;
-                hr0 = sw ? hr_l[i] : hr0;        hc0 = sw ? hc_l[i] : hc0;
-                hr[i] = sw ? hr_l[0] : hr_l[i];  hc[i] = sw ? hc_l[0] : hc_l[i];  kk[i] = sw ? kk_l[0] : kk_l[i];
-            }
-#pragma unroll
-            for (int i = 1; i < NL; ++i) { hrf[i] = (float)hr[i]; kkf[i] = (float)kk[i]; }
-            hr0f = (float)hr0;
-            // the two lower bounds of a cold start, formed on the fp32 pipe (they are only a starting guess):
-            // X <= s0 q with s0 = X'(0), and X <= hm q + asym — the fastest layer(s) (k = 0) contribute the linear term
-            // h q, every slower layer saturates at h r / sqrt(k).  Shaved so that fp32 rounding keeps them lower bounds.
-            float s0f = hr0f, hmf = hr0f, asf = 0.0f;
-#pragma unroll
-            for (int i = 1; i < NL; ++i) {
-                const bool lin = kkf[i] == 0.0f;
-                s0f += hrf[i];
-                hmf += lin ? hrf[i] : 0.0f;
-                asf += lin ? 0.0f : hrf[i] * __builtin_amdgcn_rsqf(kkf[i]);
-            }
-            rs0f = __builtin_amdgcn_rcpf(s0f) * (1.0f - 4e-6f);
-            rhmf = __builtin_amdgcn_rcpf(hmf) * (1.0f - 4e-6f);
-            asymf = asf * (1.0f + 4e-6f);
-            hc0 = valid ? hc0 : NAN;                        // target not below the element: T = NaN falls out of the sums
+    // ---- per-element records: the first wave works them out, one element per lane ----------------------
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int el = min(e0 + lane, a.n_e - 1);
+        const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0), b4 = max(el - 4, e0);
+        const double x0 = a.xe[el], z0 = a.ze[el];
+        const double x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3], x4 = a.xe[b4];
+        const double z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3], z4 = a.ze[b4];     // all loads issued together
+        // how many predecessors inside this workgroup share the element's depth (the history restarts when ze changes)
+        const bool s1 = (lane >= 1) & (z1 == z0), s2 = s1 & (lane >= 2) & (z2 == z0), s3 = s2 & (lane >= 3) & (z3 == z0),
+                   s4 = s3 & (lane >= 4) & (z4 == z0);
+        int hist = s4 ? 4 : (s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0)));
+        // Lagrange weights of the extrapolation to x0 from the nodes x1 .. x_m (differences in fp64, products in fp32)
+        const float t1 = (float)(x0 - x1), t2 = (float)(x0 - x2), t3 = (float)(x0 - x3), t4 = (float)(x0 - x4);
+        const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d14 = (float)(x1 - x4), d23 = (float)(x2 - x3),
+                    d24 = (float)(x2 - x4), d34 = (float)(x3 - x4);
+        // duplicate positions leave no slope: use as many nodes as are pairwise distinct, at least the latest one
+        const bool ok2 = d12 != 0.0f, ok3 = ok2 & (d13 != 0.0f) & (d23 != 0.0f),
+                   ok4 = ok3 & (d14 != 0.0f) & (d24 != 0.0f) & (d34 != 0.0f);
+        const int m = (hist >= 4 && ok4) ? 4 : ((hist >= 3 && ok3) ? 3 : ((hist >= 2 && ok2) ? 2 : (hist >= 1 ? 1 : 0)));
+        float w1 = 0.0f, w2 = 0.0f, w3 = 0.0f, w4 = 0.0f;
+        if (m == 4) {
+            w1 = t2 * t3 * t4 / (d12 * d13 * d14);
+            w2 = -t1 * t3 * t4 / (d12 * d23 * d24);
+            w3 = t1 * t2 * t4 / (d13 * d23 * d34);
+            w4 = -t1 * t2 * t3 / (d14 * d24 * d34);
+        } else if (m == 3) {
+            w1 = t2 * t3 / (d12 * d13);
+            w2 = -t1 * t3 / (d12 * d23);
+            w3 = t1 * t2 / (d13 * d23);
+        } else if (m == 2) {
+            w1 = t2 / d12;
+            w2 = -t1 / d12;
+        } else if (m == 1) {
+            w1 = 1.0f;
         }
-        const double dxs = xf - xe;
-        const double X = fabs(dxs);
-        // ---- Newton iteration in fp32 -----------------------------------------------------------
-        // The loop only has to bring q within ~1e-4 of the root (the fp64 expansion below removes the
-        // rest to third order), so it runs on the fp32 pipe: half the issue cost of fp64 and native
-        // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise three orders below
-        // the stopping threshold.  Lanes whose target is not below the element (!valid) carry garbage
-        // through the arithmetic (never a step: `big` is masked) and get NaN at the store.
-        const float Xf = (float)X;
-        // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
-        const float lb = fmaxf(fmaxf(Xf * rs0f, (Xf - asymf) * rhmf), 0.0f);
-        float q = lb;
-        if ((info & 3) == 2) {                              // wave-uniform
-            const float w1 = readlane_f32(w1_v, li), w2 = readlane_f32(w2_v, li), w3 = readlane_f32(w3_v, li);
-            q = fmaxf(fabsf(fmaf(w1, qs1, fmaf(w2, qs2, w3 * qs3))), lb);
-        } else if ((info & 3) == 1) {                       // one solution so far: first-order Taylor step from it —
-            const double xe1 = readlane_f64(xe_v, li - 1);  // d(qs)/d(xe) = -1 / X'(q), which the last solve left in rS3
-            q = fmaxf(fabsf(fmaf(-rS3, (float)(xe - xe1), qs1)), lb);
-        }
-        float y[NL], dq = 0.0f;                             // dq: the (small, untaken) Newton step of the last trip
-        int it = 0;
-        for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
-            const float q2 = q * q;
-            float S1 = hr0f, S3 = hr0f;                     // slot 0: k = 0, y = 1
+        // run of consecutive elements (from this one on) that all have four distinct same-depth predecessors
+        const unsigned long long m4 = __ballot(m == 4 && lane < ne);
+        const unsigned long long rest = ~(m4 >> lane);
+        const int run = (m == 4 && lane < ne) ? (rest ? __ffsll((long long)rest) - 1 : 64 - lane) : 0;
+        ElemRec r;
+        r.w1 = w1; r.w2 = w2; r.w3 = w3; r.w4 = w4; r.xe = x0;
+        r.info = m | (hist == 0 ? 8 : 0) | (run << 8);
+        r.pad = 0;
+        rec[lane] = r;
+    }
+    __syncthreads();
+
+    Lane<NL> L;
+    L.tau = INFINITY; L.rS3 = 0.0f; L.inv_cm = 0.0; L.hr0 = L.hc0 = 0.0; L.hr0f = L.rs0f = L.rhmf = L.asymf = 0.0f;
 #pragma unroll
-            for (int i = 1; i < NL; ++i) {
-                y[i] = __builtin_amdgcn_rsqf(fmaf(kkf[i], q2, 1.0f));
-                const float hw = hrf[i] * y[i];
-                S1 += hw;
-                S3 = fmaf(hw, y[i] * y[i], S3);
+    for (int i = 0; i < NL; ++i) { L.hr[i] = L.kk[i] = L.hc[i] = 0.0; L.hrf[i] = L.kkf[i] = 0.0f; }
+    float qa = 0.0f, qb = 0.0f, qc = 0.0f, qd = 0.0f;       // signed solutions of the four previous elements, qa the latest
+    const size_t nf = (size_t)a.n_f;
+    size_t o = (size_t)e0 * nf + f;                          // output index of (element e0 + li, target f)
+    int li = 0;
+    while (li < ne) {                                        // wave-uniform loop
+        const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
+        if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
+            layer_setup<NL>(a, a.ze[e0 + li], zf, L);
+            qa = qb = qc = qd = 0.0f;                        // a lane may carry NaN history from a depth at which its target
+                                                             // was not below the element
+        }
+        const int run4 = (info >> 8) & ~3;
+        if (run4 > 0) {
+            // four-history run, unrolled by four so that the history rotates through its registers without moves
+            for (int r = 0; r < run4; r += 4) {
+                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o);
+                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf);
+                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf);
+                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf);
+                o += 4 * nf;
             }
-            rS3 = __builtin_amdgcn_rcpf(S3);
-            dq = fmaf(-S1, q, Xf) * rS3;
-            // A lane is done when the step it WOULD take is small; it does not take it, so y[] stays the
-            // y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
-            const bool big = fabsf(dq) > tau * q;           // tau = +inf on !valid lanes: never a step
-            if (!__builtin_amdgcn_ballot_w64(big)) break;
-            q = big ? fmaxf(q + dq, lb) : q;
-            if (ITERS) it += big ? 1 : 0;
+            li += run4;
+        } else {
+            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o);
+            qd = qc; qc = qb; qb = qa; qa = qn;
+            o += nf;
+            ++li;
         }
-        // ---- fp64: accurate T at q + the Fermat expansion in the residual dXr = X - X(q) ----------
-        // T(root) = T(q) + p dXr + (1/2) (dp/dX) dXr^2 + O(dXr^3),
-        // p = sin(theta)/cm = q u / cm,  dp/dX = u^3 / (cm X'(q)),  u = 1/sqrt(1+q^2).
-        const double qd = (double)q;
-        const double q2 = qd * qd;
-        const double a1 = 1.0 + q2;
-        const float us = __builtin_amdgcn_rsqf(fmaf(q, q, 1.0f));   // u to 1e-7 on the fp32 pipe: seed + 2nd-order term
-        const double u = rsqrt_refine(a1, (double)us);
-        double A1 = hr0, ST = hc0;                          // slot 0: w = 1
-#pragma unroll
-        for (int i = 1; i < NL; ++i) {
-            const double w = rsqrt_refine(fma(kk[i], q2, 1.0), (double)y[i]);
-            A1 = fma(hr[i], w, A1);
-            ST = fma(hc[i], w, ST);
-        }
-        const double dXr = fma(-A1, qd, X);
-        // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
-        // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
-        const float s2 = (0.5f * us) * (us * rS3);
-        const double T = u * fma(inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
-        if (live) {
-            const size_t o = (size_t)e * a.n_f + f;
-            a.tt[o] = T;
-            if (ITERS) a.iters[o] = (uint8_t)it;
-        }
-        // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
-        const float qroot = q + dq;
-        qs3 = qs2; qs2 = qs1;
-        qs1 = __int_as_float((__float_as_int(qroot) & 0x7fffffff) | (__double2hiint(dxs) & 0x80000000));
     }
 }
 
-hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
-                                 const double* ze, int n_e, const double* xf, const double* zf, int n_f,
-                                 double* tt, uint8_t* iters, hipStream_t s)
+static hipError_t launch_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                                const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int n_batch,
+                                long long e_stride, long long f_stride, long long t_stride, hipStream_t s)
 {
+    (void)hipGetLastError();                               // a stale error of an unrelated earlier call is not this launch's
     LayerArgs a;
     for (int i = 0; i < RTUS_MAX_LAYERS; ++i) a.z_if[i] = i < n_if ? z_if[i] : INFINITY;
     for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) { a.c[i] = i <= n_if ? c[i] : 1.0; a.inv_c[i] = 1.0 / a.c[i]; }
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
     a.n_e = n_e; a.n_f = n_f;
+    a.e_stride = e_stride; a.f_stride = f_stride; a.t_stride = t_stride;
     // elements per workgroup: as many as possible (predictor + set-up reuse) while keeping >= ~4 waves per SIMD
-    const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
+    const long long wave_solves = (long long)((n_f + 63) / 64) * n_e * n_batch;
     int eb = (int)(wave_solves / (1024LL * 4));
     eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
-    while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one lane per element)
+    while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
     a.eb = eb;
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb), block(RTUS_BLOCK);
+    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb, n_batch), block(RTUS_BLOCK);
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false>), grid, block, 0, s, a); break;
@@ -294,4 +364,20 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
+                                 const double* ze, int n_e, const double* xf, const double* zf, int n_f,
+                                 double* tt, uint8_t* iters, hipStream_t s)
+{
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, s);
+}
+
+// n_batch independent problems of one shape and one medium in ONE launch (several apertures and / or target sets):
+// problem b reads xe/ze + b e_stride, xf/zf + b f_stride and writes tt + b t_stride.
+hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int n_if, const double* xe, const double* ze,
+                                       int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
+                                       long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s)
+{
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, s);
 }

@@ -75,8 +75,12 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
     import numpy as np
     z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
     c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+    if c.size != z_if.size + 1:               # the C layer reads c[0 .. n_if] from this host pointer
+        raise ValueError("need len(c) == len(z_if) + 1")
     _chk(xe, "xe"); _chk(ze, "ze"); _chk(xf, "xf"); _chk(zf, "zf")
     n_e, n_f = xe.numel(), xf.numel()
+    if ze.numel() != n_e or zf.numel() != n_f:
+        raise ValueError("xe/ze and xf/zf must pair up")
     if out is None:
         out = torch.empty((n_e, n_f), dtype=torch.float64, device=xe.device)
     _chk(out, "out")
@@ -85,6 +89,36 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
     st = _lib.lib().rtus_tt_layers_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
                                        _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
     _lib.check(st, "rtus_tt_layers_dev")
+    return out
+
+
+def tt_layers_batch_dev(z_if, c, xe, ze, xf, zf, out=None):
+    """B independent problems of one shape and one medium in ONE launch (rtus_tt_layers_batch_dev).
+
+    xe/ze: [B, n_e] or [n_e] (one aperture shared by all problems); xf/zf: [B, n_f] or [n_f] (shared) -> tt [B, n_e, n_f].
+    At least one of the two must carry the batch dimension."""
+    import numpy as np
+    z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+    if c.size != z_if.size + 1:
+        raise ValueError("need len(c) == len(z_if) + 1")
+    for t, n in ((xe, "xe"), (ze, "ze"), (xf, "xf"), (zf, "zf")):
+        _chk(t, n)
+    if xe.shape != ze.shape or xf.shape != zf.shape or xe.dim() not in (1, 2) or xf.dim() not in (1, 2):
+        raise ValueError("xe/ze and xf/zf must pair up, as [B, n] or [n]")
+    B = xe.shape[0] if xe.dim() == 2 else (xf.shape[0] if xf.dim() == 2 else None)
+    if B is None or (xe.dim() == 2 and xf.dim() == 2 and xe.shape[0] != xf.shape[0]):
+        raise ValueError("need a batch dimension on xe/ze and / or xf/zf (equal when on both)")
+    n_e, n_f = xe.shape[-1], xf.shape[-1]
+    if out is None:
+        out = torch.empty((B, n_e, n_f), dtype=torch.float64, device=xe.device)
+    _chk(out, "out")
+    if out.numel() != B * n_e * n_f:
+        raise ValueError("out has the wrong size")
+    st = _lib.lib().rtus_tt_layers_batch_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
+                                             n_e, n_e if xe.dim() == 2 else 0, _p(xf), _p(zf), n_f,
+                                             n_f if xf.dim() == 2 else 0, _p(out), n_e * n_f, B, _stream())
+    _lib.check(st, "rtus_tt_layers_batch_dev")
     return out
 
 

@@ -52,7 +52,7 @@ KERNEL(k_cnd_vcc4, asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 
 KERNEL(k_cnd_vcc4_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc"))
 KERNEL(k_cnd_salu_vcc4, asm volatile("s_mov_b64 vcc, %5\n\ts_nop 3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "s"(s01) : "vcc"))
 KERNEL(k_cnd_cmp_vcc4, asm volatile("v_cmp_gt_f32 vcc, %0, %4\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc"))
-KERNEL(k_cnd_cmp_sgpr4, { unsigned long long mk; asm volatile("v_cmp_gt_f32_e64 %5, %0, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %4, %5\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\tv_cndmask_b32_e64 %2, %2, %4, %5\n\tv_cndmask_b32_e64 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "s"(mk)); })
+KERNEL(k_cnd_cmp_sgpr4, { unsigned long long mk; asm volatile("v_cmp_gt_f32_e64 %4, %0, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %5, %4\n\tv_cndmask_b32_e64 %1, %1, %5, %4\n\tv_cndmask_b32_e64 %2, %2, %5, %4\n\tv_cndmask_b32_e64 %3, %3, %5, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(mk) : "v"(m)); })
 KERNEL(k_cnd_vcc1_fma3, asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(p) : "vcc"))
 KERNEL(k_cnd_sgpr1_fma3, asm volatile("v_cndmask_b32_e64 %0, %0, %4, %6\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(p), "s"(s01)))
 // compiler-generated selects on one per-lane condition (what the layer set-up of the planar kernel is made of)
