@@ -47,6 +47,8 @@ struct LayerArgs {
     long long e_stride, f_stride, t_stride;   // in elements of the respective arrays (0: shared by all problems)
 };
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 // Refine an fp32-pipe seed y ~ a^(-1/2) (relative error d <= ~1.5e-7: v_rsq_f32 plus the rounding of its argument)
 // with one Newton step in fp64: e = 1 - a y^2,  y <- y (1 + e/2)  -> error 1.5 d^2 <= 4e-14.  On the travel time
 // that is < 2e-18 s — an order below the O(dX^3) remainder of the expansion it feeds.
@@ -140,7 +142,7 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
 // of the wave asks for a second Newton evaluation.
 template <int NL, bool ITERS, bool FAST>
 __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, const ElemRec& R, int hist, double xf,
-                                            float h1, float h2, float h3, float h4, bool live, size_t out_index)
+                                            float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f)
 {
     const double dxs = xf - R.xe;
     const double X = fabs(dxs);
@@ -220,9 +222,14 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
     const float s2 = (0.5f * us) * (us * L.rS3);
     const double T = u * fma(L.inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
-    if (live) {
-        a.tt[out_index] = T;
-        if (ITERS) a.iters[out_index] = (uint8_t)it;
+    // store through a buffer descriptor whose base is this element's output row (wave-uniform: SGPRs) and whose
+    // extent is the row: each lane supplies a 32-bit byte offset (no 64-bit per-lane address arithmetic) and lanes
+    // beyond the last target are dropped by the range check
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.tt + row, 0, (unsigned)a.n_f * 8u, 0x00020000);
+        const u32x2 bits = {(unsigned)__double2loint(T), (unsigned)__double2hiint(T)};
+        __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, 0, 0);
+        if (ITERS && live) (a.iters + row)[f] = (uint8_t)it;
     }
     // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
     const float qroot = q + dq;
@@ -238,7 +245,7 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
 // The predictor is only a guess: iterates are clamped to the rigorous lower bound of the root,
 // from which Newton is monotone, so convergence never depends on the elements being evenly spaced.
 template <int NL, bool ITERS>   // NL = number of layers the medium has (n_if + 1)
-__global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
+__global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_tt_layers_kernel(LayerArgs a)
 {
     __shared__ ElemRec rec[64];
     // batched launch: problem blockIdx.z
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
     for (int i = 0; i < NL; ++i) { L.hr[i] = L.kk[i] = L.hc[i] = 0.0; L.hrf[i] = L.kkf[i] = 0.0f; }
     float qa = 0.0f, qb = 0.0f, qc = 0.0f, qd = 0.0f;       // signed solutions of the four previous elements, qa the latest
     const size_t nf = (size_t)a.n_f;
-    size_t o = (size_t)e0 * nf + f;                          // output index of (element e0 + li, target f)
+    size_t o = (size_t)e0 * nf;                              // output row of element e0 + li (wave-uniform)
     int li = 0;
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
@@ -321,15 +328,15 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_layers_kernel(LayerArgs a)
         if (run4 > 0) {
             // four-history run, unrolled by four so that the history rotates through its registers without moves
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o);
-                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf);
-                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf);
-                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf);
+                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o, (unsigned)f_raw);
+                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf, (unsigned)f_raw);
+                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf, (unsigned)f_raw);
+                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf, (unsigned)f_raw);
                 o += 4 * nf;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o);
+            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o, (unsigned)f_raw);
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf;
             ++li;
