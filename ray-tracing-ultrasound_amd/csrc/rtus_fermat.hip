@@ -29,6 +29,7 @@
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced; the
 // per-element data of a workgroup (coordinates, extrapolation weights) sits in LDS and is broadcast to the lanes.
 #include "rtus_device.h"
+#include <stdlib.h>
 
 struct LayerArgs {
     double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used, +inf beyond)
@@ -233,7 +234,7 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     }
     // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
     const float qroot = q + dq;
-    return __int_as_float((__float_as_int(qroot) & 0x7fffffff) | (__double2hiint(dxs) & 0x80000000));
+    return __builtin_copysignf(qroot, __int_as_float(__double2hiint(dxs)));    // one v_bfi_b32
 }
 
 // A workgroup = 256 focal points x `eb` consecutive elements (loop).  Besides re-using the layer
@@ -355,10 +356,15 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
     a.n_e = n_e; a.n_f = n_f;
     a.e_stride = e_stride; a.f_stride = f_stride; a.t_stride = t_stride;
-    // elements per workgroup: as many as possible (predictor + set-up reuse) while keeping >= ~4 waves per SIMD
+    // elements per workgroup: as many as possible (predictor + set-up reuse: the first four elements of a workgroup
+    // start Newton cold) while keeping >= ~4 waves per SIMD; 64 once that still leaves two full rounds of 8 waves per
+    // SIMD (measured on BASELINE config 3: 32 -> 64 elements per workgroup = -4.5 % time; on config 2: 8 is the optimum)
     const long long wave_solves = (long long)((n_f + 63) / 64) * n_e * n_batch;
     int eb = (int)(wave_solves / (1024LL * 4));
     eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
+    if (wave_solves >= 1024LL * 16 * 64) eb = 64;
+    static const char* const eb_override = getenv("RTUS_EB");   // experiments only (scripts/ab_planar.py)
+    if (eb_override) eb = atoi(eb_override);
     while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
     a.eb = eb;
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb, n_batch), block(RTUS_BLOCK);
