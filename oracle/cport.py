@@ -53,6 +53,8 @@ def lib():
         L.orc_lens_point.argtypes = [C.POINTER(_Lens), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lens_point.restype = None
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_trig_noise.argtypes = [C.c_uint]
+        L.orc_set_trig_noise.restype = None
         _lib = L
     return _lib
 
@@ -168,6 +170,12 @@ def trace_alpha(x_a, z_a, z_f, a, alpha_grid, r_outer, pipe_offset, flags=0, len
     lib().orc_trace_alpha(C.byref(L), r_outer, pipe_offset, float(x_a), float(z_a), float(z_f), float(a), xc, zc,
                           alpha_grid.size, flags, o)
     return o
+
+
+def set_trig_noise(mode):
+    """Sensitivity probe of the forward trace (see rt_oracle.c): two bits per trigonometric call site move its result by
+    0 / +1 / -1 / +2 ulp.  0 = plain libm — ALWAYS reset it after use."""
+    lib().orc_set_trig_noise(int(mode) & 0xffffffff)
 
 
 def num_threads():

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/rtus.h"
+#include "rtus_trig.h"
 
 #define RTUS_WAVE 64
 #define RTUS_BLOCK 256          // 4 waves per workgroup, one per SIMD
@@ -45,11 +46,11 @@ static inline LensK make_lens_k(const rtus_lens& L)
 // Lens point + tangent at polar angle alpha.
 // h:  main_rt.py:180-189 (root index [1] of roots_bhaskara :171-177)
 // dh: main_rt.py:192-214;  x,z: :217-223;  dz,dx: :226-234
-__device__ __forceinline__ void lens_eval(const LensK& k, double alpha, double& x, double& z,
-                                          double& dz, double& dx)
+// lens_eval_sc takes sin(alpha), cos(alpha): the trace needs the lens at alpha = atan2(x_i, z_i) (main_rt.py:396-397),
+// whose sine and cosine are x_i / rho and z_i / rho — no angle has to be formed at all.
+__device__ __forceinline__ void lens_eval_sc(const LensK& k, double s, double c, double& x, double& z,
+                                             double& dz, double& dx)
 {
-    double s, c;
-    sincos(alpha, &s, &c);
     double B = k.phi_3 * c - k.twoTc;              // 2 d cos(a) - 2 T c1^2/c2
     double sq = sqrt(B * B - k.C4A);
     double h = (-B - sq) / k.twoA;
@@ -61,13 +62,20 @@ __device__ __forceinline__ void lens_eval(const LensK& k, double alpha, double& 
     dz = dh * c - h * s;
     dx = dh * s + h * c;
 }
+__device__ __forceinline__ void lens_eval(const LensK& k, double alpha, double& x, double& z,
+                                          double& dz, double& dx)
+{
+    double s, c;
+    sincos(alpha, &s, &c);
+    lens_eval_sc(k, s, c, x, z, dz, dx);
+}
 
 // refraction(), angle form (main_rt.py:267-280) with the surface-slope angle already known.
 // theta_2 = asin((v2/v1) sin(theta_1)); |arg| > 1 -> NaN = total internal reflection (Q6).
 __device__ __forceinline__ double refract_angle(double phi_in, double phi_slope, double v2_over_v1)
 {
     double theta_1 = phi_in - (phi_slope + RTUS_PI_2);
-    double theta_2 = asin(v2_over_v1 * sin(theta_1));
+    double theta_2 = asin(v2_over_v1 * rtus_sin(theta_1));          // |theta_1| < 8: bounded-range kernel (rtus_trig.h)
     return phi_slope - RTUS_PI_2 + theta_2;
 }
 

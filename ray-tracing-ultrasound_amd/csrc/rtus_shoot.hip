@@ -262,6 +262,16 @@ __device__ __forceinline__ double cap_vertical(double ux, double uz)
 struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };
 struct RayOut { double xq, zq, xi, zi, x_in; };
 
+// Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan
+// through the bounded-range kernels of rtus_trig.h and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho
+// (no angle formed): 1,6xx instead of 2,066 executed VALU instructions per wave.  ONE place keeps the library's sin and
+// tan: the first refraction of a wave that holds a near-vertical refracted line (|a_pq| > 300: ~1 % of the waves).  The
+// reference intersects that line with the pipe through the quadratic formula in slope-intercept form
+// (main_rt.py:349-364), which amplifies a last-bit difference of the angle by ~|a_pq|^3 — bit-level agreement with its
+// libm decides the pipe point there, nowhere else (measured on 2.5 M random rays, the oracle with either trigonometry:
+// without this branch up to 5e-9 m apart on the pipe point above |slope| 1e4; with it <= 4e-15 m at every slope, and
+// <= 2.2e-13 m on the landing point, the level of the rays next to the critical angle).  tests/golden/edge_cfg.npz
+// `offtx`, ray 470 (a_pq = 14,217) is the fixture that finds it.
 template <bool FAST>
 __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, RayOut& out)
 {
@@ -276,8 +286,14 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     if (!FAST) {
         const double phis = in.phis;
         const double phi_ap = atan2(za - P.y, xa - P.x);               // :341
-        phi_pq = refract_angle(phi_ap, phis, k.c2 / k.c1);             // :345
-        a_pq = tan(phi_pq);                                            // :348
+        const double theta_1 = phi_ap - (phis + RTUS_PI_2);             // :267-280 refraction, tuple branch
+        phi_pq = phis - RTUS_PI_2 + asin((k.c2 / k.c1) * rtus_sin(theta_1));   // :345
+        bool steep;
+        a_pq = rtus_tan(phi_pq, steep);                                // :348
+        if (__any(steep)) {                                            // wave-uniform, rare: see the note above
+            phi_pq = phis - RTUS_PI_2 + asin((k.c2 / k.c1) * sin(theta_1));
+            a_pq = tan(phi_pq);
+        }
     } else {
 #pragma clang fp contract(fast)   // vector-form mode is not bound to NumPy's multiply-then-add rounding
         // Same law without angles.  With t = unit tangent, n = (-tz, tx), v = unit(A - P):
@@ -313,7 +329,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     if (!FAST) {
         const double phi_sl = atan(slope);                             // :287
         phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));  // :289-291
-        m = tan(phi_l);                                                // :375
+        m = rtus_tan(phi_l);                                           // :375
     } else {
 #pragma clang fp contract(fast)
         // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
@@ -466,11 +482,12 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // --- refraction water -> lens and landing on z = z_f (main_rt.py:396-405) ------------------
     double a3;
     if (!FAST) {
-        const double alpha_i = atan2(xi, zi);                          // :396
+        // :396-397 alpha_i = atan2(x_i, z_i) is only ever used through its sine and cosine: x_i / rho, z_i / rho
+        const double rho = sqrt(xi * xi + zi * zi);
         double lx, lz, ldz, ldx;
-        lens_eval(k, alpha_i, lx, lz, ldz, ldx);                       // :397 (analytic tangent at the chord point's polar angle)
+        lens_eval_sc(k, xi / rho, zi / rho, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
         const double phi_last = refract_angle(phi_l, atan2(ldz, ldx), k.c1 / k.c2);   // :398
-        a3 = tan(phi_last);                                            // :401
+        a3 = rtus_tan(phi_last);                                       // :401
     } else {
 #pragma clang fp contract(fast)
         // sin / cos of alpha_i = atan2(xi, zi) are xi/rho, zi/rho; then the refraction law as above.
@@ -497,8 +514,11 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
 
 // ---- the forward trace: one ray of the alpha grid per lane --------------------------------------
 // 6 waves per SIMD (<= 80 VGPRs; the unconstrained allocation of 81 fell one register short): measured +6 %.
+#ifndef RTUS_SHOOT_MIN_WAVES
+#define RTUS_SHOOT_MIN_WAVES 6
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void rtus_shoot_kernel(ShootArgs a)
+__global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS_SHOOT_MIN_WAVES, 8))) void rtus_shoot_kernel(ShootArgs a)
 {
     const int n = a.n;
     const int r_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;

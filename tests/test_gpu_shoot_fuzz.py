@@ -1,8 +1,8 @@
-"""GPU: randomized comparisons against the C oracle.  Forward trace (scripts/fuzz_shoot.py, 40 trials here; the
-round's long runs: 900 trials / 18 M rays): all hierarchy depths of the crossing search, tangent pipes, zero offset,
-off-centre elements, random launch grids.  NaN masks identical (except the documented noise-decided continuum at
-offset 0 on the axis), |d| <= 1e-9 (1 m + 100 |value|) — ill-conditioned single rays reach ~2e-11, a wrong segment
-would show as >= 1e-5."""
+"""GPU: randomized comparisons against the C oracle.  Forward trace (scripts/fuzz_shoot.py, 40 trials here; long runs
+are quoted in DESIGN.md): all hierarchy depths of the crossing search, tangent pipes, zero offset, off-centre elements,
+random launch grids.  Hard criterion per ray and output: |gpu - oracle| <= 1e-12 m + 16 x the oracle's own spread under
+1-2 ulp nudges of its inputs; NaN masks identical on every ray whose NaN status the oracle keeps under those nudges.  The
+self-test run moves every 97th ray onto the next polyline chord (off-by-one segment index) and must be caught."""
 import os
 import subprocess
 import sys
@@ -18,6 +18,13 @@ def test_fuzz_forward_trace_vs_oracle(rtus):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK: 40 trials" in r.stdout
+
+
+def test_fuzz_criterion_catches_a_wrong_segment(rtus):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_shoot.py"), "6", "4242", "--selftest"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, r.stdout[-2000:] + r.stderr[-2000:]          # 3 = the corruption was caught
+    assert "MISMATCH" in r.stdout
 
 
 def test_fuzz_planar_layers_vs_oracle(rtus):
