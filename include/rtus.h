@@ -10,7 +10,11 @@
  *
  * Conventions
  *   - plain C: pointers + sizes, no C++/torch types; all functions return 0 (RTUS_OK) or a
- *     negative rtus_status; nothing throws; no global mutable state; re-entrant per (device, stream).
+ *     negative rtus_status; nothing throws.  The "*_dev" entry points keep no state and are re-entrant per
+ *     (device, stream).  The host-buffer twins keep ONE thing: a per-device staging arena (a grow-only device
+ *     allocation + a non-blocking stream, created on first use, freed by rtus_release) — the reference's calling
+ *     pattern is hundreds of small sequential calls (main_rt.py:464-482), and a hipMalloc per buffer and call cost
+ *     more than the kernels.  Host-buffer calls on one device are serialised by that arena's lock.
  *   - all real data is float64 unless the name ends in _f32.
  *   - "*_dev" entry points take DEVICE pointers and a hipStream_t (passed as void*), launch
  *     asynchronously and never allocate or synchronise.  The un-suffixed twins take HOST
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUS_VERSION 100 /* 0.1.0 */
+#define RTUS_VERSION 101 /* 0.1.1 */
 
 typedef enum rtus_status {
     RTUS_OK = 0,
@@ -64,6 +68,9 @@ const char *rtus_strerror(int status);
 int rtus_version(void);
 int rtus_last_hip_error(void);
 int rtus_device_count(int *count);
+/* Frees the host-buffer twins' staging arena of `device` (all devices: -1).  Optional: a process that exits without
+ * calling it leaks nothing the driver does not reclaim. */
+int rtus_release(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Forward trace — replaces shoot_rays (main_rt.py:337-405, 432-441) and its helpers

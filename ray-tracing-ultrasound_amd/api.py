@@ -152,14 +152,31 @@ def shoot_rays(x_a, z_a, z_f, alpha, plot=False, *, params: Params = None, devic
     ``plot`` is accepted for signature compatibility; plotting (main_rt.py:407-430) is out of scope
     and the default is False so the call never blocks on a GUI.  ``options``: fast / true_tangent /
     analytic_lens as in :func:`shoot_batch` (all off = the reference's arithmetic).
+
+    The reference's driver calls this 210 times in a row (main_rt.py:464-482), so the wrapper itself is kept
+    short: one result buffer whose eight rows are the eight arrays, no per-key copies.
     """
     if plot:
         warnings.warn("rtus.shoot_rays: plotting is not part of the accelerated path; ignoring plot=True",
                       stacklevel=2)
     if np.ndim(x_a) != 0 or np.ndim(z_a) != 0:
         raise ValueError("x_a and z_a are scalars (one transmit point), as in main_rt.py:482")
-    out8 = shoot_batch([x_a], [z_a], z_f, alpha, params=params, device=device, **options)["out8"][0, 0]
-    return {k: out8[i].copy() for i, k in enumerate(KEYS)}
+    p = _resolve(params)
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    z_f = np.ascontiguousarray(z_f, dtype=np.float64)
+    if alpha.ndim != 1 or z_f.ndim != 1:
+        raise ValueError("alpha and z_f must be 1-D")
+    if alpha.shape != z_f.shape:
+        raise ValueError("alpha and z_f must have the same length")
+    if alpha.size < 2:
+        raise ValueError("Curve needs at least two points.")             # main_rt.py:26-27
+    out8 = np.empty((8, alpha.size), dtype=np.float64)
+    head = np.array([p.r_outer, p.pipe_offset, x_a, z_a], dtype=np.float64)   # geoms[1][2], x_a[1], z_a[1]
+    hp = head.ctypes.data
+    st = _lib.lib().rtus_shoot(C.byref(p.lens()), hp, 1, hp + 16, hp + 24, 1, alpha.ctypes.data, z_f.ctypes.data, alpha.size,
+                               out8.ctypes.data, None, None, None, None, _flags(**options), int(device))
+    _lib.check(st, "rtus_shoot")
+    return dict(zip(KEYS, out8))          # eight row views of one caller-owned buffer
 
 
 def match_elements(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, *, device=0):

@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <vector>
+#include <mutex>
+#include <string.h>
 #include "../../include/rtus.h"
 
 // launchers (rtus_shoot.hip / rtus_match.hip / rtus_fermat.hip)
@@ -37,36 +38,123 @@ hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi,
 static thread_local int g_last_hip = 0;
 static int hip_fail(hipError_t e) { g_last_hip = (int)e; return RTUS_ERR_HIP; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
+// a launcher reports hipGetLastError(): clear it first, so that a stale error of an unrelated earlier HIP call (the
+// caller's, torch's) is not taken for this launch's
+#define LAUNCH_TRY(x) do { (void)hipGetLastError(); HIP_TRY(x); } while (0)
 
-// RAII device buffer for the host-staging twins.
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    hipError_t upload(const void* src, size_t bytes)
-    {
-        hipError_t e = alloc(bytes);
-        return e != hipSuccess ? e : hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
-    }
-    template <class T> T* as() { return (T*)p; }
+// ---------------------------------------------------------------------------------------------------------
+// Host-buffer twins: staging through a per-device arena.  The reference's calling pattern is hundreds of small
+// sequential calls (main_rt.py:464-482: 210 x shoot_rays(N = 905)); a hipMalloc / hipFree pair per buffer and call
+// (up to 11 of them) plus the null stream's implicit synchronisation cost more than the kernels.  So: one grow-only
+// device allocation and one non-blocking stream per device, created on first use and kept until rtus_release(); a call
+// locks its device's arena for its duration (host-buffer calls on ONE device are serialised; the *_dev entry points
+// are untouched: caller's pointers, caller's stream, no state).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+constexpr size_t kPinBytes = (size_t)1 << 20;       // per direction: calls that move less than this go through ONE copy
+struct Arena {
+    std::mutex mu;
+    void* dev = nullptr;
+    size_t cap = 0;
+    char* pin = nullptr;                            // 2 x kPinBytes of page-locked host memory: [0, k) up, [k, 2k) down
+    hipStream_t stream = nullptr;
 };
+Arena g_arena[kMaxDevices];
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// The host twins run on `device` and put the caller's current device back when they return.
+// The twins run on `device` and put the caller's current device back when they return.
 struct DeviceGuard {
     int prev = -1;
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
-static int select_device_impl(int device, DeviceGuard& g)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
-    if (device < 0 || device >= n) return RTUS_ERR_NO_DEVICE;
-    int cur = -1;
-    if (hipGetDevice(&cur) == hipSuccess && cur != device) g.prev = cur;
-    HIP_TRY(hipSetDevice(device));
-    return RTUS_OK;
-}
-#define select_device(dev) select_device_impl((dev), device_guard_)
+
+struct Session {                       // one host-buffer call on one device
+    struct Xfer { void* host; size_t off, bytes; };
+    DeviceGuard guard;                 // (declared first: restored last, after the lock is gone)
+    std::unique_lock<std::mutex> lock;
+    Arena* a = nullptr;
+    size_t off = 0;
+    Xfer up[8], down[8];
+    int n_up = 0, n_down = 0;
+
+    int open(int device, size_t dev_bytes)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
+        if (device < 0 || device >= n || device >= kMaxDevices) return RTUS_ERR_NO_DEVICE;
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != device) guard.prev = cur;
+        HIP_TRY(hipSetDevice(device));
+        a = &g_arena[device];
+        lock = std::unique_lock<std::mutex>(a->mu);
+        if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+        if (!a->pin) HIP_TRY(hipHostMalloc((void**)&a->pin, 2 * kPinBytes, hipHostMallocDefault));
+        if (a->cap < dev_bytes) {                                    // grow-only; the previous call has synchronised
+            if (a->dev) { (void)hipFree(a->dev); a->dev = nullptr; a->cap = 0; }
+            const size_t want = (dev_bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+            HIP_TRY(hipMalloc(&a->dev, want));
+            a->cap = want;
+        }
+        return RTUS_OK;
+    }
+    template <class T> T* take(size_t count)                          // nullptr for count == 0
+    {
+        if (!count) return nullptr;
+        T* p = (T*)((char*)a->dev + off);
+        off += al256(count * sizeof(T));
+        return p;
+    }
+    // inputs: carved first, so they sit next to each other at the start of the arena; copied by flush()
+    template <class T> void upload(T*& d, const T* h, size_t count)
+    {
+        up[n_up++] = {(void*)h, off, count * sizeof(T)};
+        d = take<T>(count);
+    }
+    // all inputs in one host-to-device copy through the page-locked buffer when they are small (the reference's calls
+    // are: 15 KB in, 58 KB out), one copy each otherwise
+    hipError_t flush()
+    {
+        if (!n_up) return hipSuccess;
+        const size_t lo = up[0].off, span = up[n_up - 1].off + up[n_up - 1].bytes - lo;
+        if (span <= kPinBytes) {
+            for (int i = 0; i < n_up; ++i) memcpy(a->pin + (up[i].off - lo), up[i].host, up[i].bytes);
+            return hipMemcpyAsync((char*)a->dev + lo, a->pin, span, hipMemcpyHostToDevice, a->stream);
+        }
+        for (int i = 0; i < n_up; ++i) {
+            hipError_t e = hipMemcpyAsync((char*)a->dev + up[i].off, up[i].host, up[i].bytes, hipMemcpyHostToDevice, a->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    template <class T> void download(T* h, const T* d, size_t count)
+    {
+        if (h) down[n_down++] = {(void*)h, (size_t)((const char*)d - (const char*)a->dev), count * sizeof(T)};
+    }
+    // results back + synchronise: one device-to-host copy through the page-locked buffer when they are small
+    hipError_t finish()
+    {
+        if (n_down) {
+            size_t lo = down[0].off, hi = 0;
+            for (int i = 0; i < n_down; ++i) { lo = down[i].off < lo ? down[i].off : lo; hi = down[i].off + down[i].bytes > hi ? down[i].off + down[i].bytes : hi; }
+            if (hi - lo <= kPinBytes) {
+                char* stage = a->pin + kPinBytes;
+                hipError_t e = hipMemcpyAsync(stage, (char*)a->dev + lo, hi - lo, hipMemcpyDeviceToHost, a->stream);
+                if (e != hipSuccess) return e;
+                e = hipStreamSynchronize(a->stream);
+                if (e != hipSuccess) return e;
+                for (int i = 0; i < n_down; ++i) memcpy(down[i].host, stage + (down[i].off - lo), down[i].bytes);
+                return hipSuccess;
+            }
+            for (int i = 0; i < n_down; ++i) {
+                hipError_t e = hipMemcpyAsync(down[i].host, (char*)a->dev + down[i].off, down[i].bytes, hipMemcpyDeviceToHost, a->stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+        return hipStreamSynchronize(a->stream);
+    }
+};
+}   // namespace
 
 // curved-lens helpers (C++ linkage: templates)
 static int check_lens(const rtus_lens* lens, double a_lo, double a_hi, const void* xe, const void* ze, int n_e,
@@ -85,21 +173,22 @@ static int lens_host(const rtus_lens* lens, double a_lo, double a_hi, const R* x
 {
     int st = check_lens(lens, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt);
     if (st) return st;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_e * n_f;
-    DevBuf dxe, dze, dxf, dzf, dtt, dal;
-    HIP_TRY(dxe.upload(xe, sizeof(R) * n_e));
-    HIP_TRY(dze.upload(ze, sizeof(R) * n_e));
-    HIP_TRY(dxf.upload(xf, sizeof(R) * n_f));
-    HIP_TRY(dzf.upload(zf, sizeof(R) * n_f));
-    HIP_TRY(dtt.alloc(sizeof(R) * tot));
-    if (alpha_out) HIP_TRY(dal.alloc(sizeof(R) * tot));
-    HIP_TRY(launch(*lens, a_lo, a_hi, dxe.as<R>(), dze.as<R>(), n_e, dxf.as<R>(), dzf.as<R>(), n_f, dtt.as<R>(),
-                   dal.as<R>(), (hipStream_t)0));
-    HIP_TRY(hipStreamSynchronize(0));
-    HIP_TRY(hipMemcpy(tt, dtt.p, sizeof(R) * tot, hipMemcpyDeviceToHost));
-    if (alpha_out) HIP_TRY(hipMemcpy(alpha_out, dal.p, sizeof(R) * tot, hipMemcpyDeviceToHost));
+    Session S;
+    if ((st = S.open(device, 2 * al256(sizeof(R) * n_e) + 2 * al256(sizeof(R) * n_f) + (alpha_out ? 2 : 1) * al256(sizeof(R) * tot))))
+        return st;
+    R *dxe, *dze, *dxf, *dzf;
+    S.upload(dxe, xe, n_e);
+    S.upload(dze, ze, n_e);
+    S.upload(dxf, xf, n_f);
+    S.upload(dzf, zf, n_f);
+    R* dtt = S.take<R>(tot);
+    R* dal = alpha_out ? S.take<R>(tot) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(launch(*lens, a_lo, a_hi, dxe, dze, n_e, dxf, dzf, n_f, dtt, dal, S.a->stream));
+    S.download(tt, dtt, tot);
+    S.download(alpha_out, dal, tot);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -119,6 +208,26 @@ const char* rtus_strerror(int status)
 }
 int rtus_version(void) { return RTUS_VERSION; }
 int rtus_last_hip_error(void) { return g_last_hip; }
+int rtus_release(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
+    if (device >= n || device >= kMaxDevices) return RTUS_ERR_NO_DEVICE;
+    DeviceGuard guard;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) guard.prev = cur;
+    for (int d = (device < 0 ? 0 : device); d < (device < 0 ? (n < kMaxDevices ? n : kMaxDevices) : device + 1); ++d) {
+        Arena& a = g_arena[d];
+        std::lock_guard<std::mutex> lk(a.mu);
+        if (!a.dev && !a.stream && !a.pin) continue;
+        HIP_TRY(hipSetDevice(d));
+        if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); a.stream = nullptr; }
+        if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; a.cap = 0; }
+        if (a.pin) { (void)hipHostFree(a.pin); a.pin = nullptr; }
+    }
+    return RTUS_OK;
+}
+
 int rtus_device_count(int* count)
 {
     if (!count) return RTUS_ERR_INVALID_ARG;
@@ -151,7 +260,7 @@ int rtus_shoot_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, con
     if (st) return st;
     if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
     if (!d_workspace || workspace_bytes < rtus_ws_bytes(n_rays)) return RTUS_ERR_WORKSPACE;
-    HIP_TRY(rtus_launch_shoot(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_out8,
+    LAUNCH_TRY(rtus_launch_shoot(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_out8,
                               d_tof4, d_tof, d_land_x, d_status, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -163,30 +272,32 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f, n_rays);
     if (st) return st;
     if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
-    const size_t rows = (size_t)n_geom * n_tx, n = (size_t)n_rays;
-    DevBuf g, xa, za, al, zf, ws, o8, t4, tt, lx, sb;
-    HIP_TRY(g.upload(geoms, sizeof(double) * 2 * n_geom));
-    HIP_TRY(xa.upload(x_a, sizeof(double) * n_tx));
-    HIP_TRY(za.upload(z_a, sizeof(double) * n_tx));
-    HIP_TRY(al.upload(alpha, sizeof(double) * n));
-    HIP_TRY(zf.upload(z_f, sizeof(double) * n));
-    HIP_TRY(ws.alloc(rtus_ws_bytes(n_rays)));
-    if (out8) HIP_TRY(o8.alloc(sizeof(double) * rows * 8 * n));
-    if (tof4) HIP_TRY(t4.alloc(sizeof(double) * rows * 4 * n));
-    if (tof) HIP_TRY(tt.alloc(sizeof(double) * rows * n));
-    if (land_x) HIP_TRY(lx.alloc(sizeof(double) * rows * n));
-    if (status) HIP_TRY(sb.alloc(rows * n));
-    HIP_TRY(rtus_launch_shoot(*lens, g.as<double>(), n_geom, xa.as<double>(), za.as<double>(), n_tx,
-                              al.as<double>(), zf.as<double>(), n_rays, o8.as<double>(), t4.as<double>(),
-                              tt.as<double>(), lx.as<double>(), sb.as<uint8_t>(), ws.p, flags, 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    if (out8) HIP_TRY(hipMemcpy(out8, o8.p, sizeof(double) * rows * 8 * n, hipMemcpyDeviceToHost));
-    if (tof4) HIP_TRY(hipMemcpy(tof4, t4.p, sizeof(double) * rows * 4 * n, hipMemcpyDeviceToHost));
-    if (tof) HIP_TRY(hipMemcpy(tof, tt.p, sizeof(double) * rows * n, hipMemcpyDeviceToHost));
-    if (land_x) HIP_TRY(hipMemcpy(land_x, lx.p, sizeof(double) * rows * n, hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, sb.p, rows * n, hipMemcpyDeviceToHost));
+    const size_t rows = (size_t)n_geom * n_tx, n = (size_t)n_rays, rn = rows * n;
+    const size_t need = al256(16 * (size_t)n_geom) + 2 * al256(8 * (size_t)n_tx) + 2 * al256(8 * n) + al256(rtus_ws_bytes(n_rays)) +
+                        (out8 ? al256(64 * rn) : 0) + (tof4 ? al256(32 * rn) : 0) + (tof ? al256(8 * rn) : 0) +
+                        (land_x ? al256(8 * rn) : 0) + (status ? al256(rn) : 0);
+    Session S;
+    if ((st = S.open(device, need))) return st;
+    double *g, *xa, *za, *al, *zf;
+    S.upload(g, geoms, 2 * (size_t)n_geom);
+    S.upload(xa, x_a, n_tx);
+    S.upload(za, z_a, n_tx);
+    S.upload(al, alpha, n);
+    S.upload(zf, z_f, n);
+    void* ws = S.take<char>(rtus_ws_bytes(n_rays));
+    double* o8 = out8 ? S.take<double>(8 * rn) : nullptr;
+    double* t4 = tof4 ? S.take<double>(4 * rn) : nullptr;
+    double* tt = tof ? S.take<double>(rn) : nullptr;
+    double* lx = land_x ? S.take<double>(rn) : nullptr;
+    uint8_t* sb = status ? S.take<uint8_t>(rn) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_shoot(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, o8, t4, tt, lx, sb, ws, flags, S.a->stream));
+    S.download(out8, o8, 8 * rn);
+    S.download(tof4, t4, 4 * rn);
+    S.download(tof, tt, rn);
+    S.download(land_x, lx, rn);
+    S.download(status, sb, rn);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -217,7 +328,7 @@ int rtus_solve_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, con
     int st = check_solve(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt, flags);
     if (st) return st;
     if (!d_workspace || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx)) return RTUS_ERR_WORKSPACE;
-    HIP_TRY(rtus_launch_solve(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt,
+    LAUNCH_TRY(rtus_launch_solve(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt,
                               d_alpha_root, d_tt_all, d_alpha_all, d_n_roots, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -228,30 +339,35 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
 {
     int st = check_solve(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, n_rays, x_rx, n_rx, z_land, tt, flags);
     if (st) return st;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_geom * n_tx * n_rx;
-    DevBuf g, xa, za, al, rx, ws, dt, da, dta, daa, dn;
-    HIP_TRY(g.upload(geoms, sizeof(double) * 2 * n_geom));
-    HIP_TRY(xa.upload(x_a, sizeof(double) * n_tx));
-    HIP_TRY(za.upload(z_a, sizeof(double) * n_tx));
-    HIP_TRY(al.upload(alpha, sizeof(double) * n_rays));
-    HIP_TRY(rx.upload(x_rx, sizeof(double) * n_rx));
-    HIP_TRY(ws.alloc(rtus_solve_ws_bytes(n_rays, n_geom, n_tx)));
-    HIP_TRY(dt.alloc(sizeof(double) * tot));
-    if (alpha_root) HIP_TRY(da.alloc(sizeof(double) * tot));
-    if (tt_all) HIP_TRY(dta.alloc(sizeof(double) * tot * RTUS_MAX_ROOTS));
-    if (alpha_all) HIP_TRY(daa.alloc(sizeof(double) * tot * RTUS_MAX_ROOTS));
-    if (n_roots) HIP_TRY(dn.alloc(tot));
-    HIP_TRY(rtus_launch_solve(*lens, g.as<double>(), n_geom, xa.as<double>(), za.as<double>(), n_tx, al.as<double>(),
-                              n_rays, rx.as<double>(), n_rx, z_land, dt.as<double>(), da.as<double>(), dta.as<double>(),
-                              daa.as<double>(), dn.as<uint8_t>(), ws.p, flags, 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    HIP_TRY(hipMemcpy(tt, dt.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
-    if (alpha_root) HIP_TRY(hipMemcpy(alpha_root, da.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
-    if (tt_all) HIP_TRY(hipMemcpy(tt_all, dta.p, sizeof(double) * tot * RTUS_MAX_ROOTS, hipMemcpyDeviceToHost));
-    if (alpha_all) HIP_TRY(hipMemcpy(alpha_all, daa.p, sizeof(double) * tot * RTUS_MAX_ROOTS, hipMemcpyDeviceToHost));
-    if (n_roots) HIP_TRY(hipMemcpy(n_roots, dn.p, tot, hipMemcpyDeviceToHost));
+    const size_t wsb = rtus_solve_ws_bytes(n_rays, n_geom, n_tx);
+    const size_t need = al256(16 * (size_t)n_geom) + 2 * al256(8 * (size_t)n_tx) + al256(8 * (size_t)n_rays) + al256(8 * (size_t)n_rx) +
+                        al256(wsb) + al256(8 * tot) + (alpha_root ? al256(8 * tot) : 0) +
+                        (tt_all ? al256(8 * tot * RTUS_MAX_ROOTS) : 0) + (alpha_all ? al256(8 * tot * RTUS_MAX_ROOTS) : 0) +
+                        (n_roots ? al256(tot) : 0);
+    Session S;
+    if ((st = S.open(device, need))) return st;
+    double *g, *xa, *za, *al, *rx;
+    S.upload(g, geoms, 2 * (size_t)n_geom);
+    S.upload(xa, x_a, n_tx);
+    S.upload(za, z_a, n_tx);
+    S.upload(al, alpha, n_rays);
+    S.upload(rx, x_rx, n_rx);
+    void* ws = S.take<char>(wsb);
+    double* dt = S.take<double>(tot);
+    double* da = alpha_root ? S.take<double>(tot) : nullptr;
+    double* dta = tt_all ? S.take<double>(tot * RTUS_MAX_ROOTS) : nullptr;
+    double* daa = alpha_all ? S.take<double>(tot * RTUS_MAX_ROOTS) : nullptr;
+    uint8_t* dn = n_roots ? S.take<uint8_t>(tot) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_solve(*lens, g, n_geom, xa, za, n_tx, al, n_rays, rx, n_rx, z_land, dt, da, dta, daa, dn, ws, flags,
+                              S.a->stream));
+    S.download(tt, dt, tot);
+    S.download(alpha_root, da, tot);
+    S.download(tt_all, dta, tot * RTUS_MAX_ROOTS);
+    S.download(alpha_all, daa, tot * RTUS_MAX_ROOTS);
+    S.download(n_roots, dn, tot);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -272,7 +388,7 @@ int rtus_match_dev(const double* d_land_x, const double* d_tof, int n_batch, int
     int st = check_match(d_land_x, n_batch, n_rays, d_x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!d_first_ray) return RTUS_ERR_INVALID_ARG;
-    HIP_TRY(rtus_launch_match(d_land_x, d_tof, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, d_first_ray,
+    LAUNCH_TRY(rtus_launch_match(d_land_x, d_tof, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, d_first_ray,
                               d_hit, d_tof_hit, nullptr, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -283,7 +399,7 @@ int rtus_ray_hits_dev(const double* d_land_x, int n_batch, int n_rays, const dou
     int st = check_match(d_land_x, n_batch, n_rays, d_x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!d_ray_hit) return RTUS_ERR_INVALID_ARG;
-    HIP_TRY(rtus_launch_match(d_land_x, nullptr, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, nullptr,
+    LAUNCH_TRY(rtus_launch_match(d_land_x, nullptr, n_batch, n_rays, d_x_rx, n_rx, atol, rtol, nullptr,
                               nullptr, nullptr, d_ray_hit, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -294,22 +410,24 @@ int rtus_match(const double* land_x, const double* tof, int n_batch, int n_rays,
     int st = check_match(land_x, n_batch, n_rays, x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (tof_hit && !tof) return RTUS_ERR_INVALID_ARG;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays, re = (size_t)n_batch * n_rx;
-    DevBuf lx, tf, rx, fr, hb, th;
-    HIP_TRY(lx.upload(land_x, sizeof(double) * rn));
-    if (tof) HIP_TRY(tf.upload(tof, sizeof(double) * rn));
-    HIP_TRY(rx.upload(x_rx, sizeof(double) * n_rx));
-    HIP_TRY(fr.alloc(sizeof(int32_t) * re));
-    if (hit) HIP_TRY(hb.alloc(re));
-    if (tof_hit) HIP_TRY(th.alloc(sizeof(double) * re));
-    HIP_TRY(rtus_launch_match(lx.as<double>(), tf.as<double>(), n_batch, n_rays, rx.as<double>(), n_rx, atol,
-                              rtol, fr.as<int32_t>(), hb.as<uint8_t>(), th.as<double>(), nullptr, 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    if (first_ray) HIP_TRY(hipMemcpy(first_ray, fr.p, sizeof(int32_t) * re, hipMemcpyDeviceToHost));
-    if (hit) HIP_TRY(hipMemcpy(hit, hb.p, re, hipMemcpyDeviceToHost));
-    if (tof_hit) HIP_TRY(hipMemcpy(tof_hit, th.p, sizeof(double) * re, hipMemcpyDeviceToHost));
+    Session S;
+    if ((st = S.open(device, (tof ? 2 : 1) * al256(8 * rn) + al256(8 * (size_t)n_rx) + al256(4 * re) + (hit ? al256(re) : 0) +
+                                 (tof_hit ? al256(8 * re) : 0))))
+        return st;
+    double *lx, *tf = nullptr, *rx;
+    S.upload(lx, land_x, rn);
+    if (tof) S.upload(tf, tof, rn);
+    S.upload(rx, x_rx, n_rx);
+    int32_t* fr = S.take<int32_t>(re);
+    uint8_t* hb = hit ? S.take<uint8_t>(re) : nullptr;
+    double* th = tof_hit ? S.take<double>(re) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_match(lx, tf, n_batch, n_rays, rx, n_rx, atol, rtol, fr, hb, th, nullptr, S.a->stream));
+    S.download(first_ray, fr, re);
+    S.download(hit, hb, re);
+    S.download(tof_hit, th, re);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -319,17 +437,17 @@ int rtus_ray_hits(const double* land_x, int n_batch, int n_rays, const double* x
     int st = check_match(land_x, n_batch, n_rays, x_rx, n_rx, atol, rtol);
     if (st) return st;
     if (!ray_hit) return RTUS_ERR_INVALID_ARG;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
     const size_t rn = (size_t)n_batch * n_rays;
-    DevBuf lx, rx, rh;
-    HIP_TRY(lx.upload(land_x, sizeof(double) * rn));
-    HIP_TRY(rx.upload(x_rx, sizeof(double) * n_rx));
-    HIP_TRY(rh.alloc(rn));
-    HIP_TRY(rtus_launch_match(lx.as<double>(), nullptr, n_batch, n_rays, rx.as<double>(), n_rx, atol, rtol,
-                              nullptr, nullptr, nullptr, rh.as<uint8_t>(), 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    HIP_TRY(hipMemcpy(ray_hit, rh.p, rn, hipMemcpyDeviceToHost));
+    Session S;
+    if ((st = S.open(device, al256(8 * rn) + al256(8 * (size_t)n_rx) + al256(rn)))) return st;
+    double *lx, *rx;
+    S.upload(lx, land_x, rn);
+    S.upload(rx, x_rx, n_rx);
+    uint8_t* rh = S.take<uint8_t>(rn);
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_match(lx, nullptr, n_batch, n_rays, rx, n_rx, atol, rtol, nullptr, nullptr, nullptr, rh, S.a->stream));
+    S.download(ray_hit, rh, rn);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -355,7 +473,7 @@ int rtus_tt_layers_dev(const double* z_if, const double* c, int n_if, const doub
 {
     int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
     if (st) return st;
-    HIP_TRY(rtus_launch_tt_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters,
+    LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters,
                                   (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -369,7 +487,7 @@ int rtus_tt_layers_batch_dev(const double* z_if, const double* c, int n_if, cons
     if (n_batch <= 0 || e_stride < 0 || f_stride < 0) return RTUS_ERR_INVALID_ARG;
     if (n_batch > 1 && t_stride < (long long)n_e * n_f) return RTUS_ERR_INVALID_ARG;   // outputs of two problems would overlap
     if (n_batch > 65535) return RTUS_ERR_UNSUPPORTED;                                   // grid.z
-    HIP_TRY(rtus_launch_tt_layers_batch(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt,
+    LAUNCH_TRY(rtus_launch_tt_layers_batch(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt,
                                         t_stride, n_batch, (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -379,21 +497,22 @@ int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* 
 {
     int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
     if (st) return st;
-    DeviceGuard device_guard_;
-    if ((st = select_device(device))) return st;
     const size_t tot = (size_t)n_e * n_f;
-    DevBuf dxe, dze, dxf, dzf, dtt, dit;
-    HIP_TRY(dxe.upload(xe, sizeof(double) * n_e));
-    HIP_TRY(dze.upload(ze, sizeof(double) * n_e));
-    HIP_TRY(dxf.upload(xf, sizeof(double) * n_f));
-    HIP_TRY(dzf.upload(zf, sizeof(double) * n_f));
-    HIP_TRY(dtt.alloc(sizeof(double) * tot));
-    if (iters) HIP_TRY(dit.alloc(tot));
-    HIP_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe.as<double>(), dze.as<double>(), n_e, dxf.as<double>(),
-                                  dzf.as<double>(), n_f, dtt.as<double>(), dit.as<uint8_t>(), 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    HIP_TRY(hipMemcpy(tt, dtt.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
-    if (iters) HIP_TRY(hipMemcpy(iters, dit.p, tot, hipMemcpyDeviceToHost));
+    Session S;
+    if ((st = S.open(device, 2 * al256(8 * (size_t)n_e) + 2 * al256(8 * (size_t)n_f) + al256(8 * tot) + (iters ? al256(tot) : 0))))
+        return st;
+    double *dxe, *dze, *dxf, *dzf;
+    S.upload(dxe, xe, n_e);
+    S.upload(dze, ze, n_e);
+    S.upload(dxf, xf, n_f);
+    S.upload(dzf, zf, n_f);
+    double* dtt = S.take<double>(tot);
+    uint8_t* dit = iters ? S.take<uint8_t>(tot) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, S.a->stream));
+    S.download(tt, dtt, tot);
+    S.download(iters, dit, tot);
+    HIP_TRY(S.finish());
     return RTUS_OK;
 }
 
@@ -404,7 +523,7 @@ int rtus_tt_lens_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, co
 {
     int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
     if (st) return st;
-    HIP_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+    LAUNCH_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
                                     (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -415,7 +534,7 @@ int rtus_tt_lens_f32_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi
 {
     int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
     if (st) return st;
-    HIP_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+    LAUNCH_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
                                     (hipStream_t)stream));
     return RTUS_OK;
 }

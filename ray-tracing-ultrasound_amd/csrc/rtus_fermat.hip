@@ -349,7 +349,6 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
                                 const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int n_batch,
                                 long long e_stride, long long f_stride, long long t_stride, hipStream_t s)
 {
-    (void)hipGetLastError();                               // a stale error of an unrelated earlier call is not this launch's
     LayerArgs a;
     for (int i = 0; i < RTUS_MAX_LAYERS; ++i) a.z_if[i] = i < n_if ? z_if[i] : INFINITY;
     for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) { a.c[i] = i <= n_if ? c[i] : 1.0; a.inv_c[i] = 1.0 / a.c[i]; }

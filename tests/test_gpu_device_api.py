@@ -92,3 +92,35 @@ def test_caller_owned_result_buffer(rtus):
     for bad in (np.empty((16, 1199)), np.empty((16, 1200), np.float32), np.empty((1200, 16)).T):
         with pytest.raises(ValueError):
             rtus.travel_time_layers(*a, out=bad)
+
+
+def test_host_twins_reuse_one_staging_arena_and_release_it(rtus):
+    """The host-buffer twins stage through a per-device grow-only arena (rtus_capi.hip): calls of changing size, in any
+    order, before and after rtus_release(), return bit-identical results; small calls (one packed copy each way through
+    the page-locked buffer) and large ones (one copy per array) agree."""
+    L = rtus.lib()
+    n = 905
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    p = rtus.Params(r_outer=0.037, pipe_offset=0.0038)
+    first = rtus.shoot_rays(0.0, D_PLANE, zf, alpha, params=p)
+    xe = (np.arange(64) - 31.5) * 0.3e-3
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 256), np.linspace(0.026, 0.066, 256))
+    big = rtus.travel_time_layers([0.010, 0.025], [2330.0, 1483.0, 5900.0], xe, np.zeros(64), xs.ravel(), zs.ravel())   # 33 MB: grows the arena
+    again = rtus.shoot_rays(0.0, D_PLANE, zf, alpha, params=p)
+    for k in rtus.KEYS:
+        assert np.array_equal(first[k], again[k], equal_nan=True), k
+    assert L.rtus_release(0) == 0
+    after = rtus.shoot_rays(0.0, D_PLANE, zf, alpha, params=p)
+    big2 = rtus.travel_time_layers([0.010, 0.025], [2330.0, 1483.0, 5900.0], xe, np.zeros(64), xs.ravel(), zs.ravel())
+    for k in rtus.KEYS:
+        assert np.array_equal(first[k], after[k], equal_nan=True), k
+    assert np.array_equal(big, big2)
+    # a batch too large for the packed path vs the same rows one by one through it
+    xa = np.array([0.0, 0.004, -0.007])
+    b = rtus.shoot_batch(xa, np.full(3, D_PLANE), zf, np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n), np.tile([[0.037, 0.0038]], (40, 1)),
+                         params=p, want=("out8", "tof", "land_x"))
+    one = rtus.shoot_rays(0.004, D_PLANE, zf, alpha, params=p)
+    assert np.array_equal(b["out8"][17, 1], np.stack([one[k] for k in rtus.KEYS]), equal_nan=True)
+    assert L.rtus_release(-1) == 0 and L.rtus_release(0) == 0          # idempotent
+    assert L.rtus_release(10 ** 6) == -2                                # RTUS_ERR_NO_DEVICE
