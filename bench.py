@@ -743,6 +743,8 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
     res["cfg5_fmc_full"] = {"Mrays_per_s": round(nfm * 200 / dtf / 1e6, 1), "ms_per_launch": round(msf, 5), "solves_per_launch": nfm,
                             "hbm_frac": round(nfm * 8 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del outf, planf, timed
+    # --- consumers of a travel-time table: the memory-bound kernels of the library ------------------
+    res.update(consumer_measurements(dev_api, t64, torch, dev))
     # --- root-finding pulse-echo solve: the reference sweep's 210 geometries x 65 elements --------------------------
     R = ref_inputs("ref_sweep")
     sol = [None]
@@ -756,6 +758,42 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
                                    "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe"}
     # --- the reference's calling pattern: 210 sequential shoot_rays(N = 905) calls + matcher (main_rt.py:464-504) ------
     res["sweep_like_main_rt"] = sweep_like_reference(rtus)
+    return res
+
+
+def consumer_measurements(dev_api, t64, torch, dev):
+    """Focal laws over the configs[2] table (HBM-bound stream) and a TFM delay-and-sum (64 x 64 A-scans of 2048 samples,
+    256 x 256 image; L2-gather-bound), each with its own roofline."""
+    res = {}
+    W = planar_inputs("cfg3_planar", 0, 1)
+    tt3 = dev_api.tt_layers_dev(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]))
+    out = torch.empty_like(tt3)
+    ms = _event_ms(torch, lambda: dev_api.focal_delays_dev(tt3, out=out), 10)
+    n = tt3.numel()
+    res["focal_delays_cfg3"] = {"ms_per_launch": round(ms, 4), "entries": n,
+                                "roofline": {"bound": "hbm", "kernel": "rtus_focal_delays_kernel", "algorithmic_bytes_per_launch": 16 * n,
+                                             "achieved": round(16 * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(16 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "note": "8 B read + 8 B written per entry; the second read of the table (column "
+                                                     "maximum first, then subtract) is 8 B more when the strip has left the caches"}}
+    del tt3, out
+    n_el, n_t, fs = 64, 2048, 50e6
+    xe = (np.arange(n_el) - (n_el - 1) / 2.0) * 0.6e-3
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 256), np.linspace(0.025, 0.045, 256))
+    tt = dev_api.tt_layers_dev([0.020], [2330.0, 1483.0], t64(xe), t64(np.zeros(n_el)), t64(xs.ravel()), t64(zs.ravel()))
+    fmc = torch.randn((n_el, n_el, n_t), dtype=torch.float32, device=dev)
+    img = torch.empty(xs.size, dtype=torch.float32, device=dev)
+    ms = _event_ms(torch, lambda: dev_api.tfm_dev(fmc, fs, tt, out=img), 10)
+    pairs = n_el * n_el * xs.size
+    res["tfm_64x64x2048_256x256"] = {
+        "ms_per_launch": round(ms, 4), "pair_samples_per_launch": pairs, "G_pair_samples_per_s": round(pairs / (ms * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "l2-gather", "kernel": "rtus_tfm_kernel", "gathered_bytes_per_launch": 8 * pairs,
+                     "achieved": round(8 * pairs / (ms * 1e-3) / 1e9, 1), "peak": 34500.0, "unit": "GB/s (L2)",
+                     "frac": round(8 * pairs / (ms * 1e-3) / 1e9 / 34500.0, 4),
+                     "hbm_algorithmic_bytes_per_launch": fmc.numel() * 4 + tt.numel() * 8 + img.numel() * 4,
+                     "note": "two neighbouring fp32 samples (one 8-byte load) per (tx, rx, focal point); the 34 MB FMC block and the "
+                             "33 MB table are read from HBM about once and served from L2 / Infinity Cache afterwards; peak = "
+                             "aggregate L2 bandwidth of MI355X_MICROARCH.md (gathered rows shared by every workgroup reach 17-19 TB/s)"}}
     return res
 
 

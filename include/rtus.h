@@ -247,6 +247,29 @@ int rtus_tt_lens_f32(const rtus_lens *lens, double alpha_lo, double alpha_hi,
                      const float *xf, const float *zf, int n_f,
                      float *tt, float *alpha_out, int device);
 
+/* ------------------------------------------------------------------------------------------
+ * Consumers of a travel-time table.  NOT IN THE REFERENCE, which stops at the travel times
+ * (main_rt.py:497-504); checked against a NumPy restatement on synthetic point-scatterer data.
+ *
+ * rtus_focal_delays: transmit focal law, delays[e][f] = max over e' of tt[e'][f] - tt[e][f] — what element e must wait so
+ *   that all wavefronts reach focal point f together.  NaN (no ray path) is ignored by the maximum and stays NaN.
+ *   d_delays may be d_tt (in place).
+ * rtus_tfm: total-focusing-method delay-and-sum over full-matrix-capture data,
+ *   image[f] = sum over (tx, rx) of fmc[tx][rx][.] linearly interpolated at the sample position
+ *   (tt_tx[tx][f] + tt_rx[rx][f] - t0) * fs.  Samples outside a record count as zero (records are expected to be
+ *   windowed: zero at both ends); a pair without a ray path (NaN travel time) contributes nothing.
+ *     fmc     [n_tx][n_rx][n_t] float32 A-scans, fs samples per second, first sample at time t0
+ *     tt_tx   [n_tx][n_f], tt_rx [n_rx][n_f]  travel times (rtus_tt_layers* / rtus_tt_lens outputs; may be one table)
+ *     image   [n_f] float32
+ * ---------------------------------------------------------------------------------------- */
+int rtus_focal_delays_dev(const double *d_tt, int n_e, int n_f, double *d_delays, void *stream);
+int rtus_focal_delays(const double *tt, int n_e, int n_f, double *delays, int device);
+
+int rtus_tfm_dev(const float *d_fmc, int n_tx, int n_rx, int n_t, double fs, double t0,
+                 const double *d_tt_tx, const double *d_tt_rx, int n_f, float *d_image, void *stream);
+int rtus_tfm(const float *fmc, int n_tx, int n_rx, int n_t, double fs, double t0,
+             const double *tt_tx, const double *tt_rx, int n_f, float *image, int device);
+
 #ifdef __cplusplus
 }
 #endif

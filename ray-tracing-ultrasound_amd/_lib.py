@@ -86,6 +86,12 @@ def lib():
     L.rtus_tt_lens.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, dp, ip]
     L.rtus_tt_lens_f32_dev.argtypes = L.rtus_tt_lens_dev.argtypes
     L.rtus_tt_lens_f32.argtypes = L.rtus_tt_lens.argtypes
+    L.rtus_focal_delays_dev.argtypes = [dp, ip, ip, dp, vp]
+    L.rtus_focal_delays.argtypes = [dp, ip, ip, dp, ip]
+    L.rtus_tfm_dev.argtypes = [dp, ip, ip, ip, C.c_double, C.c_double, dp, dp, ip, dp, vp]
+    L.rtus_tfm.argtypes = [dp, ip, ip, ip, C.c_double, C.c_double, dp, dp, ip, dp, ip]
+    for name in ("rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm"):
+        getattr(L, name).restype = ip
     L.rtus_solve_workspace_bytes.argtypes = [ip, ip, ip]
     L.rtus_solve_workspace_bytes.restype = C.c_size_t
     L.rtus_solve_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, ip, dp, ip, C.c_double, dp, dp, dp, dp, vp, vp, C.c_size_t,
@@ -111,4 +117,5 @@ EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_
            "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
            "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_tt_layers_batch_dev",
            "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",
-           "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve")
+           "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve",
+           "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm")

@@ -315,9 +315,37 @@ def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params
     return (tt, ar, ta, aa, nr) if all_roots else (tt, ar)
 
 
-def focal_delays(tt, axis=-2):
-    """Transmit focal law from a travel-time table tt[..., n_elem, n_focal]: the delay each element must be fired
-    with so that all wavefronts reach the focal point together, delays[e, f] = max_e tt[e, f] - tt[e, f]
-    (elements without a ray path — NaN — stay NaN).  SURVEY 8(f) row 4; plain NumPy on the GPU's table."""
-    tt = np.asarray(tt, dtype=np.float64)
-    return np.nanmax(tt, axis=axis, keepdims=True) - tt
+def focal_delays(tt, *, out=None, device=0):
+    """Transmit focal law from a travel-time table tt[n_elem, n_focal]: the delay each element must be fired with so that
+    all wavefronts reach the focal point together, delays[e, f] = max_e' tt[e', f] - tt[e, f] (elements without a ray
+    path — NaN — are ignored by the maximum and stay NaN).  SURVEY 8(f) row 4; rtus_focal_delays on the GPU."""
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    if tt.ndim != 2:
+        raise ValueError("tt must be [n_elem, n_focal]")
+    d = _out(out, tt.shape, np.float64)
+    st = _lib.lib().rtus_focal_delays(_ptr(tt), tt.shape[0], tt.shape[1], _ptr(d), int(device))
+    _lib.check(st, "rtus_focal_delays")
+    return d
+
+
+def tfm_image(fmc, fs, tt_tx, tt_rx=None, *, t0=0.0, out=None, device=0):
+    """Total-focusing-method delay-and-sum over full-matrix-capture data: image[f] = sum over (tx, rx) of the A-scan
+    fmc[tx, rx, :] (float32, ``fs`` samples per second, first sample at time ``t0``) linearly interpolated at
+    tt_tx[tx, f] + tt_rx[rx, f]; tt_rx defaults to tt_tx (same aperture transmits and receives).  The travel-time tables
+    are what travel_time_layers / travel_time_lens return.  Pairs without a ray path (NaN) contribute nothing; samples
+    outside a record count as zero.  -> float32 [n_focal].  SURVEY 8(f) row 4; not in the reference."""
+    fmc = np.ascontiguousarray(fmc, dtype=np.float32)
+    if fmc.ndim != 3:
+        raise ValueError("fmc must be [n_tx, n_rx, n_t]")
+    tt_tx = np.ascontiguousarray(tt_tx, dtype=np.float64)
+    same = tt_rx is None or tt_rx is tt_tx
+    tt_rx = tt_tx if same else np.ascontiguousarray(tt_rx, dtype=np.float64)
+    if tt_tx.ndim != 2 or tt_rx.ndim != 2 or tt_tx.shape[1] != tt_rx.shape[1]:
+        raise ValueError("tt_tx / tt_rx must be [n_tx, n_focal] / [n_rx, n_focal]")
+    if tt_tx.shape[0] != fmc.shape[0] or tt_rx.shape[0] != fmc.shape[1]:
+        raise ValueError("fmc's first two dimensions must match the rows of tt_tx and tt_rx")
+    img = _out(out, (tt_tx.shape[1],), np.float32)
+    st = _lib.lib().rtus_tfm(_ptr(fmc), fmc.shape[0], fmc.shape[1], fmc.shape[2], float(fs), float(t0), _ptr(tt_tx), _ptr(tt_rx),
+                             tt_tx.shape[1], _ptr(img), int(device))
+    _lib.check(st, "rtus_tfm")
+    return img

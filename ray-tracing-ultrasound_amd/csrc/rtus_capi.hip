@@ -35,6 +35,10 @@ hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi,
                                    int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
                                    hipStream_t s);
 
+hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* delays, hipStream_t s);
+hipError_t rtus_launch_tfm(const float* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* tt_tx,
+                           const double* tt_rx, int n_f, float* image, hipStream_t s);
+
 static thread_local int g_last_hip = 0;
 static int hip_fail(hipError_t e) { g_last_hip = (int)e; return RTUS_ERR_HIP; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
@@ -512,6 +516,71 @@ int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* 
     LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, S.a->stream));
     S.download(tt, dtt, tot);
     S.download(iters, dit, tot);
+    HIP_TRY(S.finish());
+    return RTUS_OK;
+}
+
+// ---------------------------------------------------------------------------- consumers: focal laws, TFM
+static int check_tfm(const void* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const void* tt_tx, const void* tt_rx,
+                     int n_f, const void* image)
+{
+    if (!fmc || !tt_tx || !tt_rx || !image || n_tx <= 0 || n_rx <= 0 || n_t < 2 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
+    if (!(fs > 0) || !isfinite(fs) || !isfinite(t0)) return RTUS_ERR_INVALID_ARG;
+    if (n_t > (1 << 28)) return RTUS_ERR_UNSUPPORTED;                 // a record is addressed with 32-bit byte offsets
+    return RTUS_OK;
+}
+
+int rtus_focal_delays_dev(const double* d_tt, int n_e, int n_f, double* d_delays, void* stream)
+{
+    if (!d_tt || !d_delays || n_e <= 0 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
+    LAUNCH_TRY(rtus_launch_focal_delays(d_tt, n_e, n_f, d_delays, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_focal_delays(const double* tt, int n_e, int n_f, double* delays, int device)
+{
+    if (!tt || !delays || n_e <= 0 || n_f <= 0) return RTUS_ERR_INVALID_ARG;
+    const size_t tot = (size_t)n_e * n_f;
+    Session S;
+    int st = S.open(device, al256(8 * tot));
+    if (st) return st;
+    double* d;
+    S.upload(d, tt, tot);
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_focal_delays(d, n_e, n_f, d, S.a->stream));     // in place: each entry is read before it is written
+    S.download(delays, d, tot);
+    HIP_TRY(S.finish());
+    return RTUS_OK;
+}
+
+int rtus_tfm_dev(const float* d_fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* d_tt_tx,
+                 const double* d_tt_rx, int n_f, float* d_image, void* stream)
+{
+    int st = check_tfm(d_fmc, n_tx, n_rx, n_t, fs, t0, d_tt_tx, d_tt_rx, n_f, d_image);
+    if (st) return st;
+    LAUNCH_TRY(rtus_launch_tfm(d_fmc, n_tx, n_rx, n_t, fs, t0, d_tt_tx, d_tt_rx, n_f, d_image, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tfm(const float* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* tt_tx, const double* tt_rx,
+             int n_f, float* image, int device)
+{
+    int st = check_tfm(fmc, n_tx, n_rx, n_t, fs, t0, tt_tx, tt_rx, n_f, image);
+    if (st) return st;
+    const size_t nfmc = (size_t)n_tx * n_rx * n_t;
+    const bool same = tt_tx == tt_rx && n_tx == n_rx;
+    Session S;
+    if ((st = S.open(device, al256(4 * nfmc) + (same ? 1 : 2) * al256(8 * (size_t)(n_tx > n_rx ? n_tx : n_rx) * n_f) + al256(4 * (size_t)n_f))))
+        return st;
+    float* dfmc;
+    double *dtx, *drx;
+    S.upload(dfmc, fmc, nfmc);
+    S.upload(dtx, tt_tx, (size_t)n_tx * n_f);
+    if (same) drx = dtx; else S.upload(drx, tt_rx, (size_t)n_rx * n_f);
+    float* dimg = S.take<float>(n_f);
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_tfm(dfmc, n_tx, n_rx, n_t, fs, t0, dtx, drx, n_f, dimg, S.a->stream));
+    S.download(image, dimg, (size_t)n_f);
     HIP_TRY(S.finish());
     return RTUS_OK;
 }

@@ -1,0 +1,121 @@
+// rtus_tfm.hip — the consumers of a travel-time table: transmit focal laws and a total-focusing-
+// method (TFM) delay-and-sum beamformer over full-matrix-capture (FMC) data.  NOT IN THE REFERENCE (it stops at the
+// travel times, main_rt.py:497-504): checked against the NumPy restatement oracle/tfm_numpy.py on synthetic
+// point-scatterer data.
+//
+// Unlike every other kernel of this library these two are bound by memory, not by VALU issue:
+//   * rtus_focal_delays_kernel streams the table: 8 B read for the column maximum, 8 B re-read (L2 / Infinity Cache
+//     when a 256-column strip of the table fits) and 8 B written per entry -> HBM roofline, 16-24 B per entry;
+//   * rtus_tfm_kernel gathers two neighbouring fp32 samples per (tx, rx, focal point) from the A-scan of that pair:
+//     8 B of L2 traffic per pair and focal point.  The FMC block (n_tx n_rx n_t 4 B: 34 MB at 64 x 64 x 2048) is read
+//     from HBM about once per launch and then lives in L2 / Infinity Cache, so the bound is the L2 gather rate
+//     (MI355X_MICROARCH.md "Indexed rows": 17-19 TB/s chip-wide for rows shared by every workgroup), not HBM.
+#include "rtus_device.h"
+
+// ---------------------------------------------------------------------------------------------- focal laws
+// delays[e][f] = max_e' tt[e'][f] - tt[e][f]: what element e must wait so that all wavefronts reach f together.
+// NaN (no ray path) is ignored by the maximum and stays NaN in the result; a column without any path is all NaN.
+// One workgroup = 256 consecutive focal points x all elements, two passes over its strip (coalesced 2 KB rows).
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_focal_delays_kernel(const double* tt, int n_e, int n_f,
+                                                                        double* delays)   // may alias tt (in place)
+{
+    const int f = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    if (f >= n_f) return;
+    const size_t nf = (size_t)n_f;
+    double m = -INFINITY;
+    int e = 0;
+    for (; e + 4 <= n_e; e += 4) {                         // four loads in flight per lane
+        const double a = tt[(size_t)e * nf + f], b = tt[(size_t)(e + 1) * nf + f], c = tt[(size_t)(e + 2) * nf + f],
+                     d = tt[(size_t)(e + 3) * nf + f];
+        m = fmax(fmax(m, a), fmax(b, fmax(c, d)));         // fmax ignores NaN operands
+    }
+    for (; e < n_e; ++e) m = fmax(m, tt[(size_t)e * nf + f]);
+    m = (m == -INFINITY) ? NAN : m;                        // no element reaches this focal point
+    for (e = 0; e < n_e; ++e) {
+        const size_t o = (size_t)e * nf + f;
+        delays[o] = m - tt[o];                             // NaN - x and x - NaN stay NaN
+    }
+}
+
+hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* delays, hipStream_t s)
+{
+    hipLaunchKernelGGL(rtus_focal_delays_kernel, dim3((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK), dim3(RTUS_BLOCK), 0, s, tt, n_e, n_f,
+                       delays);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- TFM delay-and-sum
+// image[f] = sum over (tx, rx) of the A-scan fmc[tx][rx][.] linearly interpolated at the sample position
+// (tt_tx[tx][f] + tt_rx[rx][f] - t0) fs.  Samples outside the record count as zero; pairs without a ray path (NaN
+// travel time) contribute nothing.
+//
+// One workgroup = 256 focal points.  The receive delays (in samples, fp32) of a tile of RX_TILE elements sit in LDS,
+// lane-major (lane l reads tau[rx][l]: conflict-free); the transmit delay of the current tx is a register.  The
+// A-scan of a pair is addressed through a buffer descriptor whose base is wave-uniform (SGPRs) and whose extent is
+// the record: the hardware's range check returns 0 for a sample index outside [0, n_t) — no compare / select in the
+// inner loop — and the two neighbouring samples come in one 8-byte load.
+#define RTUS_TFM_RX_TILE 32
+typedef unsigned int tfm_u32x2 __attribute__((ext_vector_type(2)));
+
+struct TfmArgs {
+    const float* __restrict__ fmc;       // [n_tx][n_rx][n_t]
+    const double* __restrict__ tt_tx;    // [n_tx][n_f]
+    const double* __restrict__ tt_rx;    // [n_rx][n_f]
+    float* __restrict__ image;           // [n_f]
+    int n_tx, n_rx, n_t, n_f;
+    double fs;                           // samples per second
+    double half_t0s;                     // t0 * fs / 2: each of the pair's two delays carries half of the time origin
+};
+
+__device__ __forceinline__ float tfm_tau(double t, double fs, double half_t0s)
+{
+    // travel time -> half of the pair's sample position (formed in fp64, rounded once: 1e-4 of a sample at 4096
+    // samples); no path -> far outside every record (finite: the sum of two of them must not become NaN or wrap an
+    // integer conversion)
+    const float v = (float)(t * fs - half_t0s);
+    return (t == t) ? v : -1.0e8f;
+}
+
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
+{
+    __shared__ float tau_rx[RTUS_TFM_RX_TILE][RTUS_BLOCK];           // 32 KB: 5 workgroups per CU
+    const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    const bool live = f_raw < a.n_f;
+    const int f = live ? f_raw : a.n_f - 1;
+    const size_t nf = (size_t)a.n_f;
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < a.n_rx; r0 += RTUS_TFM_RX_TILE) {
+        const int nr = min(RTUS_TFM_RX_TILE, a.n_rx - r0);
+        __syncthreads();                                              // the previous tile is no longer read
+        for (int r = 0; r < nr; ++r) tau_rx[r][threadIdx.x] = tfm_tau(a.tt_rx[(size_t)(r0 + r) * nf + f], a.fs, a.half_t0s);
+        __syncthreads();
+        for (int tx = 0; tx < a.n_tx; ++tx) {
+            const float tt = tfm_tau(a.tt_tx[(size_t)tx * nf + f], a.fs, a.half_t0s);
+            const float* rec = a.fmc + ((size_t)tx * a.n_rx + r0) * (size_t)a.n_t;   // wave-uniform
+#pragma unroll 4
+            for (int r = 0; r < nr; ++r) {
+                const float s = tt + tau_rx[r][threadIdx.x];
+                const float fl = floorf(s);
+                const float w = s - fl;
+                const int i = (int)fl;                                // negative / huge: dropped by the range check
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(rec + (size_t)r * a.n_t), 0,
+                                                                                    (unsigned)a.n_t * 4u, 0x00020000);
+                const tfm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)i * 4u, 0, 0);
+                const float v0 = __uint_as_float(v.x), v1 = __uint_as_float(v.y);
+                acc += fmaf(w, v1 - v0, v0);
+            }
+        }
+    }
+    if (live) a.image[f] = acc;
+}
+
+hipError_t rtus_launch_tfm(const float* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* tt_tx,
+                           const double* tt_rx, int n_f, float* image, hipStream_t s)
+{
+    TfmArgs a;
+    a.fmc = fmc; a.tt_tx = tt_tx; a.tt_rx = tt_rx; a.image = image;
+    a.n_tx = n_tx; a.n_rx = n_rx; a.n_t = n_t; a.n_f = n_f;
+    a.fs = fs; a.half_t0s = 0.5 * t0 * fs;
+    hipLaunchKernelGGL(rtus_tfm_kernel, dim3((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK), dim3(RTUS_BLOCK), 0, s, a);
+    return hipGetLastError();
+}

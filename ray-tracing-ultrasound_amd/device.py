@@ -122,6 +122,39 @@ def tt_layers_batch_dev(z_if, c, xe, ze, xf, zf, out=None):
     return out
 
 
+def focal_delays_dev(tt, out=None):
+    """delays[e, f] = max_e' tt[e', f] - tt[e, f] on device (NaN-aware); ``out`` may be ``tt`` itself."""
+    _chk(tt, "tt")
+    if tt.dim() != 2:
+        raise ValueError("tt must be [n_elem, n_focal]")
+    if out is None:
+        out = torch.empty_like(tt)
+    _chk(out, "out")
+    if out.shape != tt.shape:
+        raise ValueError("out has the wrong shape")
+    st = _lib.lib().rtus_focal_delays_dev(_p(tt), tt.shape[0], tt.shape[1], _p(out), _stream())
+    _lib.check(st, "rtus_focal_delays_dev")
+    return out
+
+
+def tfm_dev(fmc, fs, tt_tx, tt_rx=None, t0=0.0, out=None):
+    """TFM delay-and-sum on device: fmc float32 [n_tx, n_rx, n_t], tt_tx [n_tx, n_f], tt_rx [n_rx, n_f] (default: tt_tx)
+    -> image float32 [n_f].  tt_* may be row blocks / column slices of a larger table as long as they are contiguous."""
+    _chk(fmc, "fmc", torch.float32); _chk(tt_tx, "tt_tx")
+    tt_rx = tt_tx if tt_rx is None else _chk(tt_rx, "tt_rx")
+    if fmc.dim() != 3 or tt_tx.dim() != 2 or tt_rx.dim() != 2 or tt_tx.shape[1] != tt_rx.shape[1] \
+            or fmc.shape[0] != tt_tx.shape[0] or fmc.shape[1] != tt_rx.shape[0]:
+        raise ValueError("need fmc [n_tx, n_rx, n_t], tt_tx [n_tx, n_f], tt_rx [n_rx, n_f]")
+    n_f = tt_tx.shape[1]
+    if out is None:
+        out = torch.empty(n_f, dtype=torch.float32, device=fmc.device)
+    _chk(out, "out", torch.float32)
+    st = _lib.lib().rtus_tfm_dev(_p(fmc), fmc.shape[0], fmc.shape[1], fmc.shape[2], float(fs), float(t0), _p(tt_tx), _p(tt_rx), n_f,
+                                 _p(out), _stream())
+    _lib.check(st, "rtus_tfm_dev")
+    return out
+
+
 class LayersPlan:
     """Pre-bound ``rtus_tt_layers_dev`` call for repeated solves of one shape: ``run()`` is a single
     ctypes call (no argument checking, no allocation, no sync) — capturable in a hipGraph."""
