@@ -89,6 +89,11 @@ def scaling_of(wl, world):
     return "strong" if wl in ("cfg4_lens_f32", "cfg5_fmc") else "weak"
 
 
+# RTUS_BENCH_SMALL=1 (rehearsals of the N > 1 control flow on a one-GPU box, tests/test_gpu_dist_two_ranks.py): the same
+# workloads with a few rows and a coarse grid.  Never set for a measurement: the line says so in config.workload.
+SMALL = os.environ.get("RTUS_BENCH_SMALL", "0") == "1"
+
+
 def planar_inputs(cfg, rank, world):
     """cfg2 = 128 elems @0.6 mm on z=0, interface z=20 mm, c=(2330,1483), 128x128
     focal grid over x in [-20,20] mm, z in [25,65] mm; cfg3 = 256 elems @0.3 mm, interfaces at
@@ -98,6 +103,8 @@ def planar_inputs(cfg, rank, world):
         n_e, pitch, z_if, c, g, zr = 128, 0.6e-3, [0.020], [2330.0, 1483.0], 128, (0.025, 0.065)
     else:
         n_e, pitch, z_if, c, g, zr = 256, 0.3e-3, [0.010, 0.025], [2330.0, 1483.0, 5900.0], 512, (0.026, 0.066)
+    if SMALL:
+        n_e, g = 24, 96
     n_all = n_e * world
     x_all = (np.arange(n_all) - (n_all - 1) / 2.0) * pitch
     xe = x_all[rank * n_e:(rank + 1) * n_e]
@@ -117,9 +124,12 @@ def lens_inputs(rank, world, n_rows=1024):
     water below, 1024 x 1024 target grid inside the insonified cone, fp32; tx rows sharded 1024/world per GPU (strong
     scaling: the table is fixed, each rank solves rows [lo, hi))."""
     import rtus
+    g = 1024
+    if SMALL:
+        n_rows, g = min(n_rows, 64), 128
     x_all = (np.arange(n_rows) - (n_rows - 1) / 2.0) * 0.3e-4
     lo, hi, per = _strong_rows(n_rows, rank, world)
-    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 1024), np.linspace(0.03, 0.07, 1024))
+    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, g), np.linspace(0.03, 0.07, g))
     return dict(xe=x_all[lo:hi], ze=np.full(hi - lo, rtus.Params().d), xf=xs.ravel(), zf=zs.ravel(),
                 n_e=hi - lo, n_f=xs.size, rows_total=n_rows, lo=lo)
 
@@ -130,6 +140,8 @@ def fmc_inputs(rank, world, n_tx=2048):
     z_if, c, z_r = np.array([0.008, 0.020]), np.array([2330.0, 1483.0, 5900.0]), 0.035
     z_m = np.concatenate([z_if, (2.0 * z_r - z_if)[::-1]])
     c_m = np.concatenate([c, c[::-1][1:]])
+    if SMALL:
+        n_tx = min(n_tx, 64)
     x_tx = (np.arange(n_tx) - (n_tx - 1) / 2.0) * 0.3e-3
     x_rx = (np.arange(2048) - 1023.5) * 0.3e-3
     lo, hi, per = _strong_rows(n_tx, rank, world)
@@ -418,7 +430,7 @@ def main(argv=None):
         "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32" if wl == "cfg4_lens_f32" else "f64", "data": "synthetic",
         "config": {
-            "workload": DESCR[wl] + ("" if world == 1 else
+            "workload": ("REHEARSAL SIZES (RTUS_BENCH_SMALL=1), not a measurement — " if SMALL else "") + DESCR[wl] + ("" if world == 1 else
                                      f"; {scaling}-scaled over {world} GPUs" +
                                      (f" ({units_per_step // n_f if m is not None else 0} tx rows per GPU)" if m is not None else "")),
             "solves_per_step_per_gpu": units_per_step,

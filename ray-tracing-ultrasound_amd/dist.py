@@ -42,6 +42,13 @@ class RowShardedMatrix:
         """The padded [per, n_cols] block this rank computes (rows beyond hi-lo are padding)."""
         return self.shard[slot]
 
+    def local_block(self, slot=0):
+        """(lo, hi, rows) — this rank's rows [lo, hi) of the table as a [hi-lo, n_cols] view, WITHOUT any exchange.
+        A consumer that works row by row (per-tx focal laws, a per-tx partial sum) takes this and skips ``gather``:
+        reassembling the table costs every GPU 7x its own shard over xGMI — an order of magnitude more than computing it
+        (DESIGN.md section 6)."""
+        return self.lo, self.hi, self.shard[slot][:self.hi - self.lo]
+
     def wait(self, slot=0):
         w = self._work[slot]
         if w is not None:
@@ -109,3 +116,43 @@ def travel_time_lens_sharded(xe, ze, xf, zf, *, params=None, alpha_lo=None, alph
         _lib.check(st, "rtus_tt_lens_dev")
         torch.cuda.current_stream().synchronize()          # xs / zs must outlive the launch
     return sharded_rows(xe.numel(), xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group)
+
+
+def col_shard(n_cols: int, world: int, rank: int):
+    """(lo, hi, cols_per_rank): rank owns columns (focal points) [lo, hi) of the padded world*cols_per_rank layout."""
+    return row_shard(n_cols, world, rank)
+
+
+def image_sharded(n_focal, slice_solver, *, dtype=torch.float32, device="cuda", group=None):
+    """Focal-point (column) sharding for consumers that need EVERY element's travel time per focal point — the TFM
+    delay-and-sum does: image[f] sums over all (tx, rx).  Sharding the table's rows would force the all-gather of the
+    whole table first; sharding its COLUMNS needs no exchange of travel times at all: rank r solves the table for all
+    elements on its slice of focal points, beamforms the slice, and only the image slices (4 B per focal point) are
+    all-gathered.  ``slice_solver(lo, hi, out)`` fills ``out`` ([hi-lo]) with the image of focal points [lo, hi)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi, per = col_shard(n_focal, world, rank)
+    mine = torch.zeros(per, dtype=dtype, device=device)
+    if hi > lo:
+        slice_solver(lo, hi, mine[:hi - lo])
+    if world == 1:
+        return mine[:n_focal]
+    full = torch.empty(world * per, dtype=dtype, device=device)
+    dist.all_gather_into_tensor(full, mine, group=group)
+    return full[:n_focal]
+
+
+def tfm_layers_sharded(fmc, fs, z_if, c, xe, ze, xf, zf, *, t0=0.0, group=None, table=None, beamform=None):
+    """TFM image of a layered medium across ranks with NO travel-time exchange (see :func:`image_sharded`): each rank
+    solves tt[all elements, its focal slice] with the HIP Fermat kernel and beamforms it with the HIP TFM kernel.
+    fmc [n_el, n_el, n_t] float32 and the element / focal coordinate tensors are replicated on every rank.
+    ``table`` / ``beamform`` default to the HIP kernels; the CPU (gloo) tests inject oracle stand-ins."""
+    if table is None:
+        from .device import tt_layers_dev as table
+    if beamform is None:
+        from .device import tfm_dev as beamform
+
+    def one_slice(lo, hi, out):
+        tt = table(z_if, c, xe, ze, xf[lo:hi].contiguous(), zf[lo:hi].contiguous())
+        beamform(fmc, fs, tt, None, t0, out)
+    return image_sharded(xf.numel(), one_slice, dtype=torch.float32, device=xf.device, group=group)

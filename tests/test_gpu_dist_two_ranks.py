@@ -74,3 +74,88 @@ def test_two_ranks_sharded_tables_equal_single_process(rtus):
                                   dtype=np.float32)
     assert lens.shape == one32.shape and lens.dtype == np.float32
     assert np.max(np.abs(lens.astype(np.float64) - one32.astype(np.float64))) < 1e-10
+
+
+def _run_bench_two_ranks(extra_args):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank, started BEFORE anything
+    touches the GPU), with the one-GPU rehearsal switches: both ranks on cuda:0, gloo instead of RCCL, small tables."""
+    import json
+    import subprocess
+    env = dict(os.environ, RTUS_BENCH_ONE_GPU="1", RTUS_BENCH_BACKEND="gloo", RTUS_BENCH_SMALL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_default_multi_gpu_line_strong_scaled_with_reassembly():
+    """The N > 1 control flow of bench.py: BASELINE configs[3] strong-scaled (tx rows / N), collective-free timed region,
+    the reassembly all-gather timed on its own and folded into value_with_reassembly, configs[4] under extra."""
+    d = _run_bench_two_ranks([])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f32" and d["steps"] == 4
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["solves_per_step_all_gpus"] == 2 * d["config"]["solves_per_step_per_gpu"]
+    assert d["value"] > 0 and d["reassembly"]["ms"] > 0
+    assert 0 < d["value_reassembled_every_step"] < d["value_with_reassembly"] < d["value"]
+    assert d["roofline"]["kernel"].startswith("rtus_tt_lens_kernel") and 0 < d["roofline"]["frac"] < 1
+    f = d["extra"]["cfg5_fmc"]
+    assert "error" not in f and f["rows_per_gpu"] * 2 >= 64 and f["reassembly_ms"] > 0
+
+
+def test_bench_weak_scaled_planar_and_gather_modes():
+    d = _run_bench_two_ranks(["--workload", "cfg3_planar", "--gather", "end", "--no-extra"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "configs[2]" in d["config"]["workload"]
+    assert "inside the timed region" in d["config"]["sharding"] and "reassembly" not in d
+    d = _run_bench_two_ranks(["--workload", "cfg3_planar", "--gather", "step", "--no-extra"])
+    assert "every step" in d["config"]["sharding"] and d["config"]["launch"] == "eager launches"
+
+
+def _tfm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    from oracle import tfm_numpy
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = import_module("ray-tracing-ultrasound_amd.dist")
+    n_el, n_t, fs = 16, 1500, 40e6
+    x = (np.arange(n_el) - 7.5) * 0.6e-3
+    fmc = tfm_numpy.synth_fmc(x, np.zeros(n_el), [(0.002, 0.018, 1.0)], 1483.0, fs, n_t)
+    xs, zs = np.meshgrid(np.linspace(-0.006, 0.006, 67), np.linspace(0.012, 0.024, 45))            # 3015 focal points
+    t = lambda a, dt=np.float64: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device="cuda")
+    img = d.tfm_layers_sharded(t(fmc, np.float32), fs, [0.004], [2330.0, 1483.0], t(x), t(np.zeros(n_el)), t(xs.ravel()), t(zs.ravel()))
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(img.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_column_sharded_tfm_equals_single_process(rtus):
+    """The consumer path that needs no table reassembly (dist.tfm_layers_sharded): focal points split over two ranks,
+    HIP Fermat + TFM kernels per slice, image slices gathered == the one-process image."""
+    import torch.multiprocessing as mp
+    from oracle import tfm_numpy
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tfm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    img = q.get()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    n_el, n_t, fs = 16, 1500, 40e6
+    x = (np.arange(n_el) - 7.5) * 0.6e-3
+    fmc = tfm_numpy.synth_fmc(x, np.zeros(n_el), [(0.002, 0.018, 1.0)], 1483.0, fs, n_t)
+    xs, zs = np.meshgrid(np.linspace(-0.006, 0.006, 67), np.linspace(0.012, 0.024, 45))
+    tt = rtus.travel_time_layers([0.004], [2330.0, 1483.0], x, np.zeros(n_el), xs.ravel(), zs.ravel())
+    one = rtus.tfm_image(fmc, fs, tt)
+    assert img.shape == one.shape
+    assert np.max(np.abs(img - one)) <= 1e-5 * np.max(np.abs(one))          # (slices start Newton from other predictors)
