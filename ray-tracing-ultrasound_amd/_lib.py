@@ -52,13 +52,12 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ray-tracing-ultrasound_amd/csrc`. There is no CPU fallback.")
-    # PyTorch bundles its own libamdhip64.so.7; load it first so that one HIP runtime serves both
-    # torch tensors and librtus streams/pointers in this process.
-    if "torch" not in sys.modules and os.environ.get("RTUS_NO_TORCH", "0") != "1":
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+    # The NumPy call surface (api.py, drivers.py) needs no PyTorch and does not import it.  Only device.py / dist.py do
+    # (device memory, streams, torch.distributed), at THEIR import — before the library is loaded through them, so that
+    # PyTorch's bundled libamdhip64.so.7 is the one HIP runtime of the process.  RTUS_PRELOAD_TORCH=1 forces that order
+    # for a process that starts with the NumPy API and moves to torch tensors later.
+    if os.environ.get("RTUS_PRELOAD_TORCH", "0") == "1" and "torch" not in sys.modules:
+        import torch  # noqa: F401
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
     L.rtus_strerror.argtypes = [ip]

@@ -90,10 +90,27 @@ template <typename R> __device__ __forceinline__ void sincos_r(R a, R* s, R* c);
 template <> __device__ __forceinline__ void sincos_r<float>(float a, float* s, float* c) { sincosf(a, s, c); }
 template <> __device__ __forceinline__ void sincos_r<double>(double a, double* s, double* c) { sincos(a, s, c); }
 
+// The lens constants as the solver's arithmetic reads them.  On gfx950 an fp32 VALU instruction with an SGPR operand
+// issues at half the rate of one with VGPR / inline-constant operands (4.2 vs 2.3 cycles, scripts/ubench_issue3.hip), and
+// kernel arguments live in SGPRs: the fp32 instantiation keeps per-lane (VGPR) copies, made opaque to the compiler so
+// that it does not fold them back into scalar operands.  (fp64 instructions cost 4.2 cycles either way: no copies.)
+template <typename R> struct LensConst {
+    R c1inv, c2inv, phi_3, twoTc, C4A, inv2A;
+    int poly_trig;
+};
+template <typename R> __device__ __forceinline__ LensConst<R> lens_const(const LensFermatArgs<R>& a)
+{
+    LensConst<R> k;
+    k.c1inv = a.c1inv; k.c2inv = a.c2inv; k.phi_3 = a.phi_3; k.twoTc = a.twoTc; k.C4A = a.C4A; k.inv2A = a.inv2A;
+    k.poly_trig = a.poly_trig;
+    if (sizeof(R) == 4) asm("" : "+v"(k.c1inv), "+v"(k.c2inv), "+v"(k.phi_3), "+v"(k.twoTc), "+v"(k.C4A), "+v"(k.inv2A));
+    return k;
+}
+
 // T(alpha), g = dT/dalpha and (WITH_GP) g' for one (A, F).  Without g' the second derivatives h'', P'' are skipped:
 // about a quarter of the arithmetic.
 template <typename R, bool WITH_GP>
-__device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R xa, R za, R xf, R zf, R& T, R& g,
+__device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, R za, R xf, R zf, R& T, R& g,
                                           R& gp)
 {
     R s, c;
@@ -124,38 +141,48 @@ __device__ __forceinline__ void lens_time(const LensFermatArgs<R>& k, R alpha, R
     }
 }
 
-template <typename R> __device__ __forceinline__ R readlane_r(R v, int l);
-template <> __device__ __forceinline__ float readlane_r<float>(float v, int l)
+typedef unsigned int lens_u32x2 __attribute__((ext_vector_type(2)));
+template <typename R> __device__ __forceinline__ void store_row(R* row, unsigned n_f, unsigned f, R v);
+template <> __device__ __forceinline__ void store_row<float>(float* row, unsigned n_f, unsigned f, float v)
 {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, n_f * 4u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, f * 4u, 0, 0);
 }
-template <> __device__ __forceinline__ double readlane_r<double>(double v, int l)
+template <> __device__ __forceinline__ void store_row<double>(double* row, unsigned n_f, unsigned f, double v)
 {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, n_f * 8u, 0x00020000);
+    const lens_u32x2 bits = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, 0, 0);
 }
+
+// One element's record in LDS (broadcast reads: no v_readlane, no SGPR operands — see rtus_fermat.hip).
+template <typename R> struct __attribute__((aligned(16))) LensRec {
+    R xa, za;
+    float w1, w3;            // Lagrange weights of the newest / oldest of the three previous solutions (w2 = 1 - w1 - w3)
+    int mode;                // 0: no history, 1: previous alpha, 2: extrapolate
+    int pad;
+};
 
 // A workgroup = 256 targets x `eb` consecutive elements.  The minimiser alpha*(element) is smooth in the element
 // position, so the three previous solutions extrapolate the next start (Lagrange weights from the element
-// positions, worked out once per wave by lane l for element e0 + l and fetched with v_readlane, exactly as in
+// positions, worked out once per workgroup by thread t for element e0 + t and parked in LDS, as in
 // rtus_fermat.hip): from the third element of a block on, Newton starts ~1e-7 rad from the root.
 template <typename R>
-__global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> k)
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> a)
 {
+    __shared__ LensRec<R> rec[64];
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
-    const bool live = f_raw < k.n_f;
-    const int f = live ? f_raw : k.n_f - 1;
-    const R xf = k.xf[f], zf = k.zf[f];
-    const int e0 = blockIdx.y * k.eb, e1 = min(e0 + k.eb, k.n_e);
-    const int lane = threadIdx.x & 63;
-    const int el = min(e0 + lane, k.n_e - 1);
-    const R xe_v = k.xe[el], ze_v = k.ze[el];
-    float w1_v, w3_v;                                       // Lagrange weights of the newest / oldest solution
-    int mode_v;                                             // 0: no history, 1: previous alpha, 2: extrapolate
-    {
+    const bool live = f_raw < a.n_f;
+    const int f = live ? f_raw : a.n_f - 1;
+    const R xf = a.xf[f], zf = a.zf[f];
+    const int e0 = blockIdx.y * a.eb, ne = min(a.eb, a.n_e - e0);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int el = min(e0 + lane, a.n_e - 1);
+        const R xe_v = a.xe[el], ze_v = a.ze[el];
         const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0);
-        const R x1 = k.xe[b1], x2 = k.xe[b2], x3 = k.xe[b3];
-        const R z1 = k.ze[b1], z2 = k.ze[b2], z3 = k.ze[b3];            // all loads issued together
+        const R x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3];
+        const R z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3];            // all loads issued together
         const bool s1 = (lane >= 1) & (z1 == ze_v), s2 = s1 & (lane >= 2) & (z2 == ze_v), s3 = s2 & (lane >= 3) & (z3 == ze_v);
         const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
         const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d23 = (float)(x2 - x3);
@@ -165,10 +192,18 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         const float r12 = __builtin_amdgcn_rcpf(d12);
         const float q1 = t2 * t3 * __builtin_amdgcn_rcpf(d12 * d13);
         const float q3 = t1 * t2 * __builtin_amdgcn_rcpf(d13 * d23);
-        w1_v = quad ? q1 : (lin ? t2 * r12 : 0.0f);
-        w3_v = quad ? q3 : 0.0f;
-        mode_v = lin ? 2 : (hist >= 1 ? 1 : 0);
+        LensRec<R> r;
+        r.xa = xe_v; r.za = ze_v;
+        r.w1 = quad ? q1 : (lin ? t2 * r12 : 0.0f);
+        r.w3 = quad ? q3 : 0.0f;
+        r.mode = lin ? 2 : (hist >= 1 ? 1 : 0);
+        r.pad = 0;
+        rec[lane] = r;
     }
+    __syncthreads();
+    const LensConst<R> k = lens_const<R>(a);
+    R a_lo = a.a_lo, a_hi = a.a_hi;
+    if (sizeof(R) == 4) asm("" : "+v"(a_lo), "+v"(a_hi));
     // |d alpha| below which a lane stops iterating (rad).  The step it would have taken is still applied — to alpha
     // directly and to T through the second-order term below — so what is left is third order: with
     // |d alpha| <= 1e-8 rad that is ~1e-15 rad and < 1e-25 s in fp64 (measured against the reference rays:
@@ -181,13 +216,14 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements
     R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation ...
     bool rgp_ok = false;                                    // ... usable if that solve ended at an interior minimum
-    for (int e = e0; e < e1; ++e) {
-        const int li = e - e0;
-        const int mode = __builtin_amdgcn_readlane(mode_v, li);
-        const R xa = readlane_r<R>(xe_v, li), za = readlane_r<R>(ze_v, li);
+    R* row = a.tt + (size_t)e0 * a.n_f;                     // output row of the current element (wave-uniform)
+    R* arow = a.alpha_out ? a.alpha_out + (size_t)e0 * a.n_f : nullptr;
+    for (int li = 0; li < ne; ++li) {
+        const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
+        const R xa = rec[li].xa, za = rec[li].za;
         R alpha;
         if (mode == 2) {                                    // wave-uniform
-            const float w1 = readlane_r<float>(w1_v, li), w3 = readlane_r<float>(w3_v, li);   // w2 = 1 - w1 - w3
+            const float w1 = rec[li].w1, w3 = rec[li].w3;   // w2 = 1 - w1 - w3
             // differences first: alpha* varies slowly, so the weights (3, -3, 1 on an even pitch) act on small numbers
             alpha = al1 + ((R)(w1 - 1.0f) * (al1 - al2) + (R)w3 * (al3 - al2));
         } else if (mode == 1) {
@@ -198,8 +234,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             const R t = (za - hz) / (za - zf);
             alpha = atan2(xa + t * (xf - xa), hz);
         }
-        alpha = fmin(fmax(alpha, k.a_lo), k.a_hi);
-        R lo = k.a_lo, hi = k.a_hi, T, g, gp = R(0);
+        alpha = fmin(fmax(alpha, a_lo), a_hi);
+        R lo = a_lo, hi = a_hi, T, g, gp = R(0);
         // Extrapolated start and a usable g' in every lane: evaluate T and g only and take the Newton step with the
         // g' of the previous element (g' varies by ~1e-3 from one element to the next; it only scales a step that is
         // already below the stopping tolerance).  If any lane's step is not small, the wave runs the full iteration.
@@ -230,11 +266,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         const R dal = interior ? -g * rgp : R(0);
         if (interior) T += R(0.5) * g * dal;
         const R asol = alpha + dal;
-        if (live) {
-            const size_t o = (size_t)e * k.n_f + f;
-            k.tt[o] = T;
-            if (k.alpha_out) k.alpha_out[o] = asol;
-        }
+        // stores through a descriptor on the element's output row: 32-bit lane offsets, lanes past the last target dropped
+        store_row<R>(row, (unsigned)a.n_f, (unsigned)f_raw, T);
+        if (arow) { store_row<R>(arow, (unsigned)a.n_f, (unsigned)f_raw, asol); arow += a.n_f; }
+        row += a.n_f;
         al3 = al2; al2 = al1; al1 = asol;
     }
 }

@@ -15,6 +15,10 @@ D_PLANE = float(np.float64(0.12156646438729327) + np.float64(0.08843353561270673
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GPU sessions mix the NumPy API and the torch-tensor API in one process: load PyTorch's HIP runtime first (the
+    # library itself no longer imports torch: _lib.lib()).
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        import torch  # noqa: F401
 
 
 def load_golden(name):

@@ -92,3 +92,14 @@ def test_drivers_on_gpu():
     _check_database(drv.rows_to_csv(drv.sweep_database()))
     header, rows = drv.compare_rows()
     _check_compare(drv.rows_to_csv(rows, header))
+
+
+@pytest.mark.gpu
+def test_compare_against_database_on_gpu():
+    """The MSE tail of main_compare.py (:485-500, 526-553) on the HIP backend, with the reference's compare.csv standing
+    in for the absent database.csv: same configuration -> per-ray errors at rounding level, num_hitted = 393, mse ~ 0."""
+    drv = import_module("ray-tracing-ultrasound_amd.drivers")
+    err, num_hitted, mse = drv.compare_against_database(os.path.join(GOLDEN, "compare.csv"))
+    assert err.shape == (1810,) and num_hitted == 393
+    assert np.isnan(err).sum() == 385
+    assert np.nanmax(np.abs(err)) < 1e-15 and mse < 1e-30
