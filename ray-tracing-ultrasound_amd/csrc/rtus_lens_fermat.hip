@@ -289,6 +289,7 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
     int eb = (int)(wave_solves / (1024LL * 4));
     k.eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
+    if (wave_solves >= 1024LL * 16 * 64) k.eb = 64;         // large tables: halves the cold starts per solve (cf. rtus_fermat.hip)
     while ((n_e + k.eb - 1) / k.eb > 65535 && k.eb < 64) ++k.eb;   // grid.y limit (eb <= 64: one lane per element)
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + k.eb - 1) / k.eb);
     hipLaunchKernelGGL(rtus_tt_lens_kernel<R>, grid, dim3(RTUS_BLOCK), 0, s, k);
