@@ -710,6 +710,22 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
                           "note": "500 back-to-back launches replayed as a hipGraph; the 16.8 MB result fits the 256 MiB Infinity "
                                   "Cache, so this 'HBM' fraction is fabric traffic, not DRAM traffic"}
     del out2, plan2, timed
+    # the same problem size through the batched entry: 8 apertures (the array shifted in x) x one target grid per launch
+    B = 8
+    xe8 = t64(np.stack([W["xe"] + 0.3e-3 * b for b in range(B)]))
+    ze8 = t64(np.zeros((B, W["n_e"])))
+    xf8, zf8 = t64(W["xf"]), t64(W["zf"])
+    out8 = torch.empty((B, W["n_e"], W["n_f"]), dtype=torch.float64, device=dev)
+    runb = lambda: dev_api.tt_layers_batch_dev(W["z_if"], W["c"], xe8, ze8, xf8, zf8, out=out8)
+    for _ in range(3):
+        runb()
+    torch.cuda.synchronize()
+    timedb = Timed(torch, lambda s: runb(), 200)
+    dtb, msb = timedb.run(lambda: None)
+    res["cfg2_planar_batch8"] = {"Mrays_per_s": round(B * n2 * 200 / dtb / 1e6, 1), "ms_per_launch": round(msb, 5),
+                                 "solves_per_launch": B * n2, "hbm_frac": round(B * n2 * 8 / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "rtus_tt_layers_batch_dev: 8 config-2-sized problems (8 apertures, one target grid) in ONE launch"}
+    del out8, timedb
     # --- BASELINE configs[3]: curved-lens two-point Fermat solves, fp32: the whole 1024 x 1024^2 table on one GPU (the
     # N = 1 point of the strong-scaling series bench.py --gpus N runs) and the 128-row shard one of 8 GPUs solves ------
     lens = rtus.Params().lens()
