@@ -1,90 +1,178 @@
-"""Turns the rocprofv3 databases scripts/profile_round.sh leaves under gpurun_out/prof_<tag>/ into the small
-text files committed under profiles/ (run in the build container after the gpurun call):
+"""Turns the rocprofv3 CSV output scripts/profile_round.sh leaves under gpurun_out/prof_<tag>/ into the small files
+committed under profiles/ (run in the build container after the gpurun call):
 
-    python scripts/profile_summarise.py r01
+    python scripts/profile_summarise.py r02
 """
-import csv, json, os, sqlite3, sys
+import collections
+import csv
+import glob
+import json
+import os
+import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 
 
-def db(name):
-    d = os.path.join(src, name)
-    f = [x for x in os.listdir(d) if x.endswith(".db")][0]
-    return sqlite3.connect(os.path.join(d, f))
+def rows_of(sub, suffix):
+    out = []
+    for f in glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
 
 
-def kernel_stats(name, out):
-    c = db(name)
-    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
-                     "group by name order by sum(duration) desc").fetchall()
-    tot = sum(r[2] for r in rows)
-    with open(os.path.join(dst, out), "w", newline="") as fh:
+def kernel_rows(sub, label, like="rtus_"):
+    """per-kernel duration statistics of one traced run (one workload size per run)"""
+    acc = collections.defaultdict(list)
+    for r in rows_of(sub, "kernel_trace.csv"):
+        if like in r["Kernel_Name"]:
+            acc[(r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"],
+                 r["LDS_Block_Size"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = []
+    for (name, gx, gy, gz, vg, sg, sc, lds), d in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        d = sorted(d)
+        out.append({"run": label, "kernel": name, "grid": f"{gx}x{gy}x{gz}", "calls": len(d), "avg_ns": round(sum(d) / len(d), 1),
+                    "median_ns": d[len(d) // 2], "min_ns": d[0], "max_ns": d[-1], "vgprs": vg, "sgprs": sg, "scratch": sc, "lds": lds})
+    return out
+
+
+def counters(subs, like):
+    """mean counter values per dispatch of the kernels matching `like`, merged over several passes
+    (+ "_duration_ns:<counter>": mean dispatch duration in the pass that collected <counter>)"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for sub in subs:
+        for r in rows_of(sub, "counter_collection.csv"):
+            if like in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"]]["_duration_ns:" + r["Counter_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                meta[r["Kernel_Name"]] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, meta
+
+
+def write_counters(path, table, meta):
+    with open(path, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
-        for r in rows:
-            w.writerow([r[0], r[1], r[2], round(r[3], 1), r[4], r[5], round(100.0 * r[2] / tot, 3)])
-    return {r[0]: r for r in rows}
+        w.writerow(["Kernel", "Counter", "MeanPerDispatch", "GridSize", "WorkgroupSize", "VGPRs", "SGPRs", "Scratch", "LDS"])
+        for k in sorted(table):
+            for c in sorted(table[k]):
+                if not c.startswith("_duration_ns:"):
+                    w.writerow([k, c, round(table[k][c], 2)] + list(meta[k]))
 
 
-def counters(name, out, like="%rtus_%"):
-    c = db(name)
-    rows = c.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration), "
-                     "min(grid_size), min(workgroup_size), min(vgpr_count), min(sgpr_count) "
-                     "from counters_collection where kernel_name like ? group by kernel_name, counter_name "
-                     "order by kernel_name, counter_name", (like,)).fetchall()
-    with open(os.path.join(dst, out), "w", newline="") as fh:
-        w = csv.writer(fh)
-        w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch", "Min", "Max", "MeanDurationNs(profiled)",
-                    "GridSize", "WorkgroupSize", "VGPRs", "SGPRs"])
-        for r in rows:
-            w.writerow([r[0], r[1], r[2], round(r[3], 2), r[4], r[5], round(r[6], 1), r[7], r[8], r[9], r[10]])
-    return {(r[0], r[1]): r[3] for r in rows}
+def write_rows(path, rows):
+    if not rows:
+        return
+    with open(path, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
 
 
-ks = kernel_stats("kt", f"{tag}_bench_cfg2_kernel_stats.csv")
-wr = counters("wr", f"{tag}_pmc_WRITE_SIZE_cfg2.csv")
-rd = counters("rd", f"{tag}_pmc_FETCH_SIZE_cfg2.csv")
-sq = counters("sq", f"{tag}_pmc_sq_cfg2.csv")
-wr3 = counters("wr3", f"{tag}_pmc_WRITE_SIZE_cfg3.csv") if os.path.isdir(os.path.join(src, "wr3")) else {}
-rd3 = counters("rd3", f"{tag}_pmc_FETCH_SIZE_cfg3.csv") if os.path.isdir(os.path.join(src, "rd3")) else {}
-s0 = counters("sq_shoot0", f"{tag}_pmc_shoot_refscale_sq_compat.csv")
-s1 = counters("sq_shoot1", f"{tag}_pmc_shoot_refscale_sq_fast.csv")
+# ---- bench lines ---------------------------------------------------------------------------------------------
+for name in ("bench_k20", "bench_default"):
+    line = open(os.path.join(src, name + ".json")).read().strip().splitlines()[-1]
+    json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
+bench = json.load(open(os.path.join(dst, f"{tag}_bench_k20.json")))
 
-head = [k for k in ks if "rtus_tt_layers_kernel<2, false>" in k][0]
-w_kib = wr[(head, "WRITE_SIZE")]
-r_kib = rd[(head, "FETCH_SIZE")]
-bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+# ---- kernel trace of the driver's command ------------------------------------------------------------------------
+kt = kernel_rows("kt", "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)")
+write_rows(os.path.join(dst, f"{tag}_bench_kernel_trace.csv"), kt)
+head = [r for r in kt if "rtus_tt_layers_kernel<3, false>" in r["kernel"]][0]
+
+# ---- HBM traffic of the headline launch --------------------------------------------------------------------------
+wr, m1 = counters(["wr"], "rtus_tt_layers_kernel<3, false>")
+rd, m2 = counters(["rd"], "rtus_tt_layers_kernel<3, false>")
+write_counters(os.path.join(dst, f"{tag}_pmc_WRITE_SIZE_cfg3.csv"), wr, m1)
+write_counters(os.path.join(dst, f"{tag}_pmc_FETCH_SIZE_cfg3.csv"), rd, m2)
+hk = list(wr)[0]
+w_kib, r_kib = wr[hk]["WRITE_SIZE"], rd[hk]["FETCH_SIZE"]
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 traffic = {
-    "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python3 bench.py --steps 20 --warmup 5 "
-            "--graph off` (MI355X_MICROARCH.md HBM section): counters are in KiB per dispatch; on gfx950 FETCH_SIZE reports half "
-            "of the bytes of a coalesced read stream, so it is doubled; WRITE_SIZE is exact for coalesced stores (here 8 B/lane: "
-            "2,097,152 x 8 B = 16,384 KiB reproduced exactly, which calibrates the store side on this access pattern).",
-    "kernel": "rtus_tt_layers_kernel<2, false>",
-    "FETCH_SIZE_KiB_raw": round(r_kib, 2),
-    "WRITE_SIZE_KiB": round(w_kib, 2),
-    "cfg2_planar": int(round((2 * r_kib + w_kib) * 1024)),
-    "algorithmic_bytes_per_launch": alg,
+    "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python3 bench.py --steps 5 --warmup 2 --graph off "
+            "--no-extra --no-cpu-baseline` (MI355X_MICROARCH.md HBM section): counters are KiB per dispatch; on gfx950 FETCH_SIZE reports "
+            "half of the bytes of a coalesced read stream, so it is doubled; WRITE_SIZE is exact for coalesced stores (67,108,864 x 8 B = "
+            "524,288 KiB reproduced exactly, which calibrates the store side on this access pattern).",
+    "kernel": hk, "FETCH_SIZE_KiB_raw": round(r_kib, 2), "WRITE_SIZE_KiB": round(w_kib, 2),
+    "cfg3_planar": int(round((2 * r_kib + w_kib) * 1024)), "algorithmic_bytes_per_launch": alg,
 }
-head3 = [k[0] for k in wr3 if "rtus_tt_layers_kernel<3, false>" in k[0]]
-if head3 and (head3[0], "FETCH_SIZE") in rd3:
-    traffic["cfg3_planar"] = int(round((2 * rd3[(head3[0], "FETCH_SIZE")] + wr3[(head3[0], "WRITE_SIZE")]) * 1024))
-    traffic["cfg3_algorithmic_bytes_per_launch"] = 256 * 262144 * 8 + (2 * 256 + 2 * 262144) * 8
-    traffic["cfg3_FETCH_SIZE_KiB_raw"] = round(rd3[(head3[0], "FETCH_SIZE")], 2)
-    traffic["cfg3_WRITE_SIZE_KiB"] = round(wr3[(head3[0], "WRITE_SIZE")], 2)
+cw, _ = counters(["wr_cons"], "rtus_")
+cr, _ = counters(["rd_cons"], "rtus_")
+for k in cw:
+    short = "tfm" if "tfm" in k else ("focal_delays" if "focal" in k else None)
+    if short and k in cr:
+        traffic[short + "_bytes_per_launch"] = int(round((2 * cr[k]["FETCH_SIZE"] + cw[k]["WRITE_SIZE"]) * 1024))
+        traffic[short + "_FETCH_SIZE_KiB_raw"] = round(cr[k]["FETCH_SIZE"], 1)
+        traffic[short + "_WRITE_SIZE_KiB"] = round(cw[k]["WRITE_SIZE"], 1)
 json.dump(traffic, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
-json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
 
-print("headline kernel:", head, "calls", ks[head][1], "avg ns", round(ks[head][3], 1))
-print("bench.py HIP-event mean (un-profiled) us:", bench["roofline"]["avg_launch_ms"] * 1e3, " value", bench["value"])
-print("traffic:", traffic["cfg2_planar"], "vs algorithmic", alg, "| cfg3:", traffic.get("cfg3_planar"), "vs", traffic.get("cfg3_algorithmic_bytes_per_launch"))
-for label, d in (("planar", sq), ("shoot compat", s0), ("shoot fast", s1)):
-    for kn in sorted({k[0] for k in d}):
-        g = lambda n: d.get((kn, n), float("nan"))
-        wv = g("SQ_WAVES")
-        print(f"{label}: {kn[:60]:60s} waves {wv:9.0f}  VALU/wave {g('SQ_INSTS_VALU')/wv:8.1f}  SALU/wave {g('SQ_INSTS_SALU')/wv:8.1f}  "
-              f"VALU-active cyc/wave {4*g('SQ_ACTIVE_INST_VALU')/wv:8.0f}  wave cyc {4*g('SQ_WAVE_CYCLES')/wv:8.0f}  busy cyc {4*g('SQ_BUSY_CYCLES'):10.0f}")
+# ---- SQ counters: headline kernel and the other table kernels ------------------------------------------------------
+sq, meta = counters(["sq", "sq2", "sq3"], "rtus_tt_layers_kernel<3, false>")
+write_counters(os.path.join(dst, f"{tag}_pmc_sq_cfg3.csv"), sq, meta)
+valu = {}
+c = sq[hk]
+waves = c["SQ_WAVES"]
+solves = 256 * 262144
+wave_solves = solves / 64.0
+f64 = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"]
+trans = c["SQ_INSTS_VALU_TRANS_F32"]
+cvt = c["SQ_INSTS_VALU_CVT"]
+f32 = c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]
+other = c["SQ_INSTS_VALU"] - f64 - trans - cvt - f32
+# issue cycles per wave-instruction measured by scripts/ubench_issue*.hip (8 waves per SIMD): fp64 4.2, v_rsq/v_rcp_f32 8.2,
+# cvt 4.2, fp32 fma/mul/add with VGPR operands 2.3, everything else (moves, bit ops, compares, max) 2.3 .. 4.2 -> 3.3
+issue = f64 * 4.2 + trans * 8.2 + cvt * 4.2 + f32 * 2.3 + other * 3.3
+kern_ns = head["avg_ns"]
+# effective clock of the profiled launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+clock = c["GRBM_GUI_ACTIVE"] / 8.0 / c["_duration_ns:GRBM_GUI_ACTIVE"]
+sq_ns = c["_duration_ns:SQ_WAVE_CYCLES"]
+valu["cfg3_planar"] = {
+    "kernel": hk,
+    "insts_valu_per_solve": round(c["SQ_INSTS_VALU"] / wave_solves, 2),
+    "insts_valu_per_solve_by_class": {"fp64_fma_mul_add": round(f64 / wave_solves, 2), "fp32_fma_mul_add": round(f32 / wave_solves, 2),
+                                      "trans_f32": round(trans / wave_solves, 2), "cvt": round(cvt / wave_solves, 2),
+                                      "other": round(other / wave_solves, 2)},
+    "insts_salu_per_solve": round(c["SQ_INSTS_SALU"] / wave_solves, 2),
+    "insts_lds_per_solve": round(c.get("SQ_INSTS_LDS", 0) / wave_solves, 2),
+    "issue_cycles_per_wave_solve": round(issue / wave_solves, 1),
+    "issue_cycles_how": "instruction classes (SQ_INSTS_VALU_*) x issue cycles per wave-instruction measured by scripts/ubench_issue*.hip "
+                        "(profiles/%s_ubench_issue.txt)" % tag,
+    "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+    "waves": int(waves), "waves_per_simd_launched": round(waves / 1024.0, 1),
+    "valu_active_x_resident_waves": round(8 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3),
+    "wave_life_us_mean": round(4 * c["SQ_WAVE_CYCLES"] / waves / (clock * 1e3), 2),
+    "wave_slots_occupied_frac_of_kernel": round((4 * c["SQ_WAVE_CYCLES"] / (clock * 1e9)) / (8 * 1024 * sq_ns * 1e-9), 3),
+    "profiled_launch_us": round(sq_ns / 1e3, 1),
+    "clock_ghz": round(clock, 3),
+    "clock_how": "GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the counter pass (reads a few % high on dispatches this short)",
+}
+json.dump(valu, open(os.path.join(dst, f"valu_{tag}.json"), "w"), indent=1)
+for wl, like in (("cfg4_lens_f32", "rtus_tt_lens_kernel"), ("cfg2_planar", "rtus_tt_layers_kernel"), ("cfg5_fmc", "rtus_tt_layers_kernel")):
+    t, m = counters([f"sq_{wl}"], like)
+    write_counters(os.path.join(dst, f"{tag}_pmc_sq_{wl}.csv"), t, m)
+
+# ---- forward trace: one size per row -------------------------------------------------------------------------------
+shoot = (kernel_rows("kt_shoot0", "reference geometry 1024 tx x 8192 rays, reference-compatible arithmetic (scripts/run_shoot_once.py 0)") +
+         kernel_rows("kt_shoot1", "reference geometry 1024 tx x 8192 rays, vector-form arithmetic (scripts/run_shoot_once.py 1)") +
+         kernel_rows("kt_sweep", "the reference's own sweep, 210 geometries x 905 rays (bench.py --workload ref_sweep --graph off)"))
+write_rows(os.path.join(dst, f"{tag}_shoot_kernel_rows.csv"), shoot)
+for mode, name in ((0, "compat"), (1, "fast")):
+    t, m = counters([f"sq_shoot{mode}"], "rtus_shoot_kernel")
+    write_counters(os.path.join(dst, f"{tag}_pmc_shoot_refscale_sq_{name}.csv"), t, m)
+    for k, cs in t.items():
+        print(f"shoot {name}: VALU/wave {cs['SQ_INSTS_VALU'] / cs['SQ_WAVES']:.0f}  SALU/wave {cs['SQ_INSTS_SALU'] / cs['SQ_WAVES']:.0f}")
+write_rows(os.path.join(dst, f"{tag}_consumers_kernel_rows.csv"), kernel_rows("kt_cons", "scripts/run_consumers_once.py"))
+
+# ---- instruction issue costs ----------------------------------------------------------------------------------------
+with open(os.path.join(dst, f"{tag}_ubench_issue.txt"), "w") as fh:
+    for n in ("ubench_issue", "ubench_issue2", "ubench_issue3"):
+        fh.write(f"==== scripts/{n}.hip ====\n" + open(os.path.join(src, n + ".txt")).read() + "\n")
+
+print("headline kernel:", hk, "| kernel-trace avg ns", head["avg_ns"], "median", head["median_ns"], "calls", head["calls"])
+print("bench.py (un-profiled, K=20): value", bench["value"], "ms/step", bench["ms_per_step"], "avg_launch_ms", bench["roofline"]["avg_launch_ms"],
+      "frac", bench["roofline"]["frac"])
+print("traffic:", traffic["cfg3_planar"], "vs algorithmic", alg, "->", round(traffic["cfg3_planar"] / alg, 4))
+print("valu:", json.dumps(valu["cfg3_planar"], indent=1))
+print({k: v for k, v in traffic.items() if k.startswith(("tfm", "focal"))})
