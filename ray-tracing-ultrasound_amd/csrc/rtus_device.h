@@ -16,6 +16,7 @@
 struct LensK {
     double c1, c2, d;
     double inv_c1, inv_c2;   // 1/c1, 1/c2 (host-rounded; used by the vector-form mode only)
+    double eta12, eta21;     // c1/c2, c2/c1: the refraction ratios of main_rt.py:398 / :345, divided once on the host
     double A;        // c1^2/c2^2 - 1                    main_rt.py:183
     double C4A;      // 4*A*C, C = c1^2 T^2 - d^2        main_rt.py:185, 172
     double twoA;     // 2*A                              main_rt.py:173
@@ -30,6 +31,7 @@ static inline LensK make_lens_k(const rtus_lens& L)
     LensK k;
     k.c1 = L.c1; k.c2 = L.c2; k.d = L.d;
     k.inv_c1 = 1.0 / L.c1; k.inv_c2 = 1.0 / L.c2;
+    k.eta12 = L.c1 / L.c2; k.eta21 = L.c2 / L.c1;
     double T = L.l0 / L.c1 + L.h0 / L.c2;
     double c1sq = L.c1 * L.c1;
     k.A = c1sq / (L.c2 * L.c2) - 1.0;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void lens_eval(const LensK& k, double alpha, double& 
 __device__ __forceinline__ double refract_angle(double phi_in, double phi_slope, double v2_over_v1)
 {
     double theta_1 = phi_in - (phi_slope + RTUS_PI_2);
-    double theta_2 = asin(v2_over_v1 * rtus_sin(theta_1));          // |theta_1| < 8: bounded-range kernel (rtus_trig.h)
+    double theta_2 = rtus_asin(v2_over_v1 * rtus_sin(theta_1));     // |theta_1| < 8: bounded-range kernels (rtus_trig.h)
     return phi_slope - RTUS_PI_2 + theta_2;
 }
 

@@ -285,13 +285,17 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     double phi_pq = 0.0;
     if (!FAST) {
         const double phis = in.phis;
-        const double phi_ap = atan2(za - P.y, xa - P.x);               // :341
+        const double eta = k.eta21;                                     // c2 / c1, host-rounded (the same IEEE division)
+        const double phi_ap = rtus_atan2(za - P.y, xa - P.x);           // :341
         const double theta_1 = phi_ap - (phis + RTUS_PI_2);             // :267-280 refraction, tuple branch
-        phi_pq = phis - RTUS_PI_2 + asin((k.c2 / k.c1) * rtus_sin(theta_1));   // :345
+        const double sn = eta * rtus_sin(theta_1);
+        // entering the slower medium |eta sin| stays below 1/2: the wave-uniform test drops asin's second form
+        phi_pq = phis - RTUS_PI_2 + (eta < 0.5 ? rtus_asin_small(sn) : rtus_asin(sn));   // :345
         bool steep;
         a_pq = rtus_tan(phi_pq, steep);                                // :348
         if (__any(steep)) {                                            // wave-uniform, rare: see the note above
-            phi_pq = phis - RTUS_PI_2 + asin((k.c2 / k.c1) * sin(theta_1));
+            const double th = atan2(za - P.y, xa - P.x) - (phis + RTUS_PI_2);
+            phi_pq = phis - RTUS_PI_2 + asin(eta * sin(th));
             a_pq = tan(phi_pq);
         }
     } else {
@@ -301,7 +305,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         // direction at phi_pq = phi_s - pi/2 + theta_2 is  u = -n cos(theta_2) + t sin(theta_2).
         const double2 t = in.tu;
         const double vx = xa - P.x, vz = za - P.y;
-        const double s2 = -(k.c2 / k.c1) * (t.x * vx + t.y * vz) * rsqrt_fast(vx * vx + vz * vz);
+        const double s2 = -k.eta21 * (t.x * vx + t.y * vz) * rsqrt_fast(vx * vx + vz * vz);
         const double c2 = m_sqrt<true>(1.0 - s2 * s2);
         uz = -t.x * c2 + t.y * s2;
         ux = cap_vertical(t.y * c2 + t.x * s2, uz);
@@ -327,7 +331,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
                               : -xt / sqrt(r_outer * r_outer - xt * xt);   // :237-238
     double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
     if (!FAST) {
-        const double phi_sl = atan(slope);                             // :287
+        const double phi_sl = rtus_atan(slope);                        // :287
         phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));  // :289-291
         m = rtus_tan(phi_l);                                           // :375
     } else {
@@ -486,7 +490,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         const double rho = sqrt(xi * xi + zi * zi);
         double lx, lz, ldz, ldx;
         lens_eval_sc(k, xi / rho, zi / rho, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
-        const double phi_last = refract_angle(phi_l, atan2(ldz, ldx), k.c1 / k.c2);   // :398
+        const double phi_last = refract_angle(phi_l, rtus_atan2(ldz, ldx), k.eta12);   // :398
         a3 = rtus_tan(phi_last);                                       // :401
     } else {
 #pragma clang fp contract(fast)
@@ -501,7 +505,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         double tz = dh * ci - h * si, tx_ = dh * si + h * ci;          // (dz, dx)
         const double rt = rsqrt_fast(tx_ * tx_ + tz * tz);
         tx_ *= rt; tz *= rt;
-        const double s2 = -(k.c1 / k.c2) * (tx_ * lx_u + tz * lz_u);   // u_l is a unit vector
+        const double s2 = -k.eta12 * (tx_ * lx_u + tz * lz_u);   // u_l is a unit vector
         const double c2 = m_sqrt<true>(1.0 - s2 * s2);                 // NaN = total internal reflection
         const double w3z = -tx_ * c2 + tz * s2;
         a3 = w3z * rcp_fast(cap_vertical(tz * c2 + tx_ * s2, w3z));

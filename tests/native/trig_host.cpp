@@ -6,3 +6,11 @@ void t_sin(const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i]
 void t_cos(const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i] = rtus_cos(x[i]); }
 void t_tan(const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i] = rtus_tan(x[i]); }
 }
+extern "C" {
+void t_asin(const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i] = rtus_asin(x[i]); }
+void t_atan(const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i] = rtus_atan(x[i]); }
+void t_atan2(const double* y, const double* x, int n, double* o) { for (int i = 0; i < n; ++i) o[i] = rtus_atan2(y[i], x[i]); }
+// max error in ulps of the result against the long-double library, over n samples (bulk accuracy sweeps)
+double t_err_asin(const double* x, int n) { double m = 0; for (int i = 0; i < n; ++i) { long double r = asinl((long double)x[i]); double v = rtus_asin(x[i]); double u = fabs((double)((long double)v - r)) / (nextafter(fabs((double)r), INFINITY) - fabs((double)r)); if (u > m) m = u; } return m; }
+double t_err_atan2(const double* y, const double* x, int n) { double m = 0; for (int i = 0; i < n; ++i) { long double r = atan2l((long double)y[i], (long double)x[i]); double v = rtus_atan2(y[i], x[i]); double u = fabs((double)((long double)v - r)) / (nextafter(fabs((double)r), INFINITY) - fabs((double)r)); if (u > m) m = u; } return m; }
+}
