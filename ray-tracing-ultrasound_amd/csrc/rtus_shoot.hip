@@ -9,6 +9,7 @@
 //   node1   double4[n/64]     ... of 64 points
 //   node2   double4[n/512]    ... of 512 points
 //   node3   double4[n/4096]   ... of 4096 points (long polylines only)
+//   tree    TreeNode[n0+n1+n2+n3]  the same boxes in depth-first order with skip links (what the crossing search walks)
 //   out8    [n_geom][n_tx][8][n]   SoA per (geometry, tx): every store is a coalesced 512-B row
 //
 // Crossing search (reference find_line_curve_intersection, main_rt.py:78-99: FIRST index j with
@@ -37,12 +38,13 @@ struct ShootArgs {
     const double4* __restrict__ node1;  // [n1]
     const double4* __restrict__ node2;  // [n2]
     const double4* __restrict__ node3;  // [n3] 4096-point boxes, only built when n2 > 8 (else n3 = 0)
+    const struct TreeNode* __restrict__ tree;   // [n0 + n1 + n2 + n3] the boxes in depth-first order (see TreeNode)
     double* __restrict__ out8;          // nullable
     double* __restrict__ tof4;          // nullable
     double* __restrict__ tof;           // nullable
     double* __restrict__ land_x;        // nullable
     uint8_t* __restrict__ status;       // nullable
-    int n, n_tx, n_geom, n0, n1, n2, n3;
+    int n, n_tx, n_geom, n0, n1, n2, n3, n_tree;
     unsigned flags;
 };
 
@@ -114,6 +116,63 @@ __global__ void rtus_node3_kernel(const double4* __restrict__ node2, int n2, dou
     node3[i] = make_box(xmin, xmax, zmin, zmax);
 }
 
+// The box hierarchy in depth-first (pre-order) order, one 64-byte record per box: what the crossing search walks.  A visit
+// is ONE scalar load at a wave-uniform index i; the next index is i + 1 (first child / next leaf) while some ray is
+// still undecided about this box and `skip` (the record after this box's whole subtree) once every ray is decided — a
+// single loop without per-level counters, bounds or address arithmetic: on gfx950 the scalar ALU issues one instruction per
+// ~4.4 cycles per SIMD (scripts/ubench_issue4.hip) and the nested-loop form of this walk spent ~25 scalar instructions per
+// box, three times the cost of the box test itself.
+// Only the LAST subtree of a level can be incomplete (boxes group consecutive points), so with the full-subtree sizes
+// 1, 9, 73, 585 the record of box k of level L sits at  t sz[top] + sum over the levels l below the top of
+// (1 + digit_l(k) sz[l])  — every box computes its own place, no scan.
+struct __attribute__((aligned(64))) TreeNode {
+    double xc, xh, zc, zh;        // the box: centre / half-extent
+    int j0;                       // its first polyline point
+    unsigned skip_off;            // byte offset of the record after this box's subtree
+    unsigned long long leafm;     // all ones: an 8-point unit; 0: an inner box (a lane mask, so the walk needs no branch on it)
+    int j1;                       // one past its last polyline point
+    int pad[3];
+};
+// The record after the last box carries the polyline's extent instead of a box: xc = max |x|, xh = max |z| (the rounding
+// part of the certification margin).
+
+__global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double4* __restrict__ node1,
+                                 const double4* __restrict__ node2, const double4* __restrict__ node3,
+                                 int n0, int n1, int n2, int n3, TreeNode* __restrict__ tree)
+{
+    const int total = n0 + n1 + n2 + n3;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    int L, k;
+    const double4* src;
+    if (id < n0) { L = 0; k = id; src = node0; }
+    else if (id < n0 + n1) { L = 1; k = id - n0; src = node1; }
+    else if (id < n0 + n1 + n2) { L = 2; k = id - n0 - n1; src = node2; }
+    else { L = 3; k = id - n0 - n1 - n2; src = node3; }
+    const int top = n3 > 0 ? 3 : 2;
+    const int sz[4] = {1, 9, 73, 585};
+    int pos = (k >> (3 * (top - L))) * sz[top];
+    for (int l = top - 1; l >= L; --l) pos += 1 + ((k >> (3 * (l - L))) & 7) * sz[l];
+    const double4 b = src[k];
+    TreeNode t;
+    t.xc = b.x; t.xh = b.y; t.zc = b.z; t.zh = b.w;
+    t.j0 = k << (3 * (L + 1)); t.j1 = t.j0 + (8 << (3 * L));
+    t.skip_off = (unsigned)min(pos + sz[L], total) * (unsigned)sizeof(TreeNode);
+    t.leafm = L == 0 ? ~0ull : 0ull;
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    tree[pos] = t;
+    if (pos == 0) {
+        TreeNode e = t;
+        e.xc = 0.0; e.xh = 0.0;
+        for (int q = 0; q < n2; ++q) {
+            const double4 bx = node2[q];
+            e.xc = fmax(e.xc, fabs(bx.x) + bx.y);
+            e.xh = fmax(e.xh, fabs(bx.z) + bx.w);
+        }
+        tree[total] = e;
+    }
+}
+
 // Crossing search state.  The reference wants the first j with sign(d_j) != sign(d_{j+1})
 // (main_rt.py:82, 99).  Every point before that change has the class c0 = np.sign(d_0) of polyline
 // point 0, so equivalently: p = the first polyline point whose class differs from c0, idx = p - 1.
@@ -132,7 +191,7 @@ struct Walk {
     // reads d > 0 (multiplying by +-1 is exact: every certification decision is the one the unsigned form makes)
     double ms, bs, sg, am;
     double marg;             // certification margin; +inf for rays with d_0 == 0 exactly (class 0 is never certified)
-    int slot;                // per lane: 8-point unit (j >> 3) where the lane left the walk — found there, or parked on it
+    int slot;                // per lane: first point of the box where the lane left the walk — found there, or parked on that leaf
     int start;               // per lane: polyline points before this index are known to have class c0
     lanemask active;         // rays still walking
     lanemask pend;           // rays parked on the leaf `slot`
@@ -159,58 +218,43 @@ __device__ __forceinline__ void known_prefix(const Walk& W, int j0, int j1, lane
     neg &= ~(before | partly);
 }
 
-// Visit an inner box (first polyline point j0).  Rays certified "opposite" are found (p = j0) and leave the walk;
-// returns the rays that could not be decided here (the caller descends if there are any).
-template <bool RETRY>
-__device__ __forceinline__ lanemask visit(Walk& W, const double4 bx, int j0, int j1)
+// One lock-step pass over the box hierarchy, boxes in index order (depth-first records, see TreeNode).  At an inner box
+// the rays certified "opposite" are found (p = its first point) and leave the walk; the wave descends only if some ray
+// could not be decided.  At a leaf (8 points) every ray that is not certified "same" leaves the walk — found, or parked
+// on the leaf to look at its points itself.  RETRY = a pass after the first (rays whose parked leaf held no change resume
+// behind it): compiled separately so that the first pass, which is nearly always the only one, carries none of the
+// prefix bookkeeping.
+// One record into SGPRs: ONE scalar-memory instruction at base + byte offset (the compiler's own form of tree[i] is a 64-bit
+// shift / add / add-with-carry in front of two or three narrower loads).  Not volatile (a volatile asm is a memory clobber
+// and would turn every later wave-uniform load of the kernel into a vector load); the tree is read-only here.
+typedef int v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ TreeNode load_record(const TreeNode* __restrict__ base, unsigned off)
 {
-    lanemask pos, neg;
-    certify(W, bx, W.marg, pos, neg);
-    if (RETRY) known_prefix(W, j0, j1, pos, neg);
-    const lanemask diff = W.active & neg;
-    W.active &= ~neg;
-    W.slot = lane_bit(diff) ? (j0 >> 3) : W.slot;
-    return W.active & ~pos;
-}
-// Visit a leaf box (8 points, unit U): every ray that is not certified "same" leaves the walk here — found
-// (certified opposite: p = 8 U) or parked on the leaf to look at its points itself.
-template <bool RETRY>
-__device__ __forceinline__ void visit_leaf(Walk& W, const double4 bx, int U)
-{
-    lanemask pos, neg;
-    certify(W, bx, W.marg, pos, neg);
-    if (RETRY) known_prefix(W, U * 8, U * 8 + 8, pos, neg);
-    const lanemask out = W.active & ~pos;
-    W.active &= pos;
-    W.pend |= out & ~neg;
-    W.slot = lane_bit(out) ? U : W.slot;
+    v16i r;
+    asm("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(base), "s"(off));
+    return __builtin_bit_cast(TreeNode, r);
 }
 
-// One lock-step pass over the box hierarchy (4096 / 512 / 64 / 8 points), boxes in index order.  RETRY = a pass after
-// the first (rays whose parked leaf held no change resume behind it): compiled separately so that the first pass,
-// which is nearly always the only one, carries none of the prefix bookkeeping.
-struct WalkBoxes { const double4* node0; const double4* node1; const double4* node2; const double4* node3; int n0, n1, n2, n3; };
 template <bool RETRY>
-__device__ __forceinline__ void walk_pass(Walk& W, const WalkBoxes& a)
+__device__ __forceinline__ void walk_pass(Walk& W, const TreeNode* __restrict__ tree, int n_tree)
 {
-    const int nT = a.n3 > 0 ? a.n3 : 1;
-    for (int T3 = 0; T3 < nT && W.active; ++T3) {
-        if (a.n3 > 0 && !visit<RETRY>(W, a.node3[T3], T3 * 4096, T3 * 4096 + 4096)) continue;
-        const int S0 = a.n3 > 0 ? T3 * 8 : 0, S1 = a.n3 > 0 ? min(T3 * 8 + 8, a.n2) : a.n2;
-        for (int S = S0; S < S1 && W.active; ++S) {
-            DBG(0);
-            if (!visit<RETRY>(W, a.node2[S], S * 512, S * 512 + 512)) continue;
-            const int B1 = min(S * 8 + 8, a.n1);
-            for (int B = S * 8; B < B1 && W.active; ++B) {
-                DBG(1);
-                if (!visit<RETRY>(W, a.node1[B], B * 64, B * 64 + 64)) continue;
-                const int U1 = min(B * 8 + 8, a.n0);
-                for (int U = B * 8; U < U1; ++U) {
-                    DBG(2);
-                    visit_leaf<RETRY>(W, a.node0[U], U);
-                }
-            }
-        }
+    const unsigned end = (unsigned)n_tree * (unsigned)sizeof(TreeNode);
+    unsigned off = 0;
+    while (off < end && W.active) {
+        const TreeNode nd = load_record(tree, off);
+        DBG(0);
+        lanemask pos, neg;
+        certify(W, make_double4(nd.xc, nd.xh, nd.zc, nd.zh), W.marg, pos, neg);
+        if (RETRY) known_prefix(W, nd.j0, nd.j1, pos, neg);
+        // inner box: rays certified "opposite" are found here (p = j0), the wave descends if some ray is undecided;
+        // leaf: every ray not certified "same" leaves — found, or parked on the leaf.  One formula, leafm = all / none:
+        const lanemask np = W.active & ~pos, und = np & ~neg;
+        const lanemask gone = np & (neg | nd.leafm);
+        W.pend |= und & nd.leafm;
+        W.active &= ~gone;
+        W.slot = lane_bit(gone) ? nd.j0 : W.slot;
+        const unsigned next = off + (unsigned)sizeof(TreeNode);
+        off = (und & ~nd.leafm) ? next : max(nd.skip_off, next);   // (max: the walk advances whatever the record holds)
     }
 }
 
@@ -346,14 +390,8 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
 
     // --- first sign change of d_j along the polyline (main_rt.py:78-99) -----------------------
     const bool fin = isfinite(m) && isfinite(b);   // non-finite line -> the reference ends in (None, None)
-    // polyline extent (for the rounding part of the margin): a handful of wave-uniform box reads
-    double xabs = 0.0, zabs = 0.0;
-    for (int s = 0; s < a.n2; ++s) {
-        const double4 bx = a.node2[s];
-        xabs = fmax(xabs, fabs(bx.x) + bx.y);
-        zabs = fmax(zabs, fabs(bx.z) + bx.w);
-    }
-    const WalkBoxes boxes = {a.node0, a.node1, a.node2, a.node3, a.n0, a.n1, a.n2, a.n3};
+    // polyline extent (for the rounding part of the margin): kept in the first record of the tree
+    const double xabs = a.tree[a.n_tree].xc, zabs = a.tree[a.n_tree].xh;
     Walk W;
     // 2e-8 >= the reference's isclose(d, 0) atol, so a skipped box can hold no "point on the line"
     // (main_rt.py:86); the relative part is ~450x the worst fp64 rounding of d_j.
@@ -377,32 +415,39 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // union of all 64 rays' leaves point by point.
     for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
         const lanemask active0 = W.active;
-        if (pass == 0) walk_pass<false>(W, boxes); else walk_pass<true>(W, boxes);
+        if (pass == 0) walk_pass<false>(W, a.tree, a.n_tree); else walk_pass<true>(W, a.tree, a.n_tree);
         // rays a box answered during this pass: p = first point of that box.  Rays still active walked off the
         // end: no class change anywhere, idx stays -1.
-        idx = lane_bit(active0 & ~W.active & ~W.pend) ? W.slot * 8 - 1 : idx;
+        idx = lane_bit(active0 & ~W.active & ~W.pend) ? W.slot - 1 : idx;
         W.active = 0;
         if (!W.pend) break;
         DBG(3);
         // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
         // point: a copy never changes class, so the padding cannot produce a hit).
         const bool mine = lane_bit(W.pend);
-        const double2* __restrict__ cp = a.curve + (size_t)W.slot * 8;
+        const double2* __restrict__ cp = a.curve + W.slot;
         double2 c[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) c[i] = cp[i];                        // 8 gathers in flight together
         int hit = -1;
+        if (!c0zero) {
+            // np.sign(d_j) != c0 with the line in its signed form (sg d > 0 <=> "same class as point 0"; the products by
+            // +-1 are exact): one multiply, one fma, one compare and the select per point, nothing on the scalar unit
 #pragma unroll
-        for (int i = 7; i >= 0; --i) {
-            const double t = fma(m, c[i].x, b);
-            // np.sign(d_j) != c0, as lane masks: class + must stay >, class - must stay <, class 0 must stay ==
-            const lanemask differs = (c0pos & ~__ballot(c[i].y > t)) | (c0neg & ~__ballot(c[i].y < t)) |
-                                     (c0zero & __ballot(c[i].y != t));
-            hit = lane_bit(differs) ? i : hit;
+            for (int i = 7; i >= 0; --i) hit = (W.sg * c[i].y > fma(W.ms, c[i].x, W.bs)) ? hit : i;
+        } else {
+            // some ray's point 0 lies exactly on its line (class 0 must stay ==): the three-class form, as lane masks
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                const double t = fma(m, c[i].x, b);
+                const lanemask differs = (c0pos & ~__ballot(c[i].y > t)) | (c0neg & ~__ballot(c[i].y < t)) |
+                                         (c0zero & __ballot(c[i].y != t));
+                hit = lane_bit(differs) ? i : hit;
+            }
         }
         const bool got = mine && hit >= 0;
-        idx = got ? W.slot * 8 + hit - 1 : idx;
-        W.start = (mine && !got) ? W.slot * 8 + 8 : W.start;             // nothing here: resume after this leaf
+        idx = got ? W.slot + hit - 1 : idx;
+        W.start = (mine && !got) ? W.slot + 8 : W.start;             // nothing here: resume after this leaf
         W.active = __ballot(mine && !got);
         W.pend = 0;
         if (!W.active) break;
@@ -715,7 +760,26 @@ static size_t ws_node0_off(int n) { return align32(ws_tanu_off(n) + (size_t)n * 
 static size_t ws_node1_off(int n) { return ws_node0_off(n) + (size_t)((n + 7) / 8) * sizeof(double4); }
 static size_t ws_node2_off(int n) { return ws_node1_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
 static size_t ws_node3_off(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
-size_t rtus_ws_bytes(int n) { return ws_node3_off(n) + (size_t)((n + 4095) / 4096) * sizeof(double4); }
+static int n_tree_nodes(int n) { return (n + 7) / 8 + (n + 63) / 64 + (n + 511) / 512 + (n + 4095) / 4096 + 1; }   // upper bound (node3 may be unused) + the extent record
+static size_t ws_tree_off(int n) { return (ws_node3_off(n) + (size_t)((n + 4095) / 4096) * sizeof(double4) + 63) & ~(size_t)63; }
+size_t rtus_ws_bytes(int n) { return ws_tree_off(n) + (size_t)n_tree_nodes(n) * sizeof(TreeNode); }
+
+// Workspace pointers and sizes of a ShootArgs (the workspace base must be 64-byte aligned: hipMalloc gives 256).
+static void shoot_args_workspace(ShootArgs& a, char* w, int n)
+{
+    a.curve = (const double2*)w;
+    a.phi_s = (const double*)(w + ws_phis_off(n));
+    a.tan_u = (const double2*)(w + ws_tanu_off(n));
+    a.node0 = (const double4*)(w + ws_node0_off(n));
+    a.node1 = (const double4*)(w + ws_node1_off(n));
+    a.node2 = (const double4*)(w + ws_node2_off(n));
+    a.node3 = (const double4*)(w + ws_node3_off(n));
+    a.tree = (const TreeNode*)(w + ws_tree_off(n));
+    a.n = n;
+    a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
+    a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
+    a.n_tree = a.n0 + a.n1 + a.n2 + a.n3;
+}
 
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
@@ -726,22 +790,16 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     ShootArgs a;
     a.k = make_lens_k(lens);
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f;
-    a.curve = (const double2*)w;
-    a.phi_s = (const double*)(w + ws_phis_off(n));
-    a.tan_u = (const double2*)(w + ws_tanu_off(n));
-    a.node0 = (const double4*)(w + ws_node0_off(n));
-    a.node1 = (const double4*)(w + ws_node1_off(n));
-    a.node2 = (const double4*)(w + ws_node2_off(n));
-    a.node3 = (const double4*)(w + ws_node3_off(n));
+    shoot_args_workspace(a, w, n);
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
-    a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
-    a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
-    a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
+    a.n_tx = n_tx; a.n_geom = n_geom;
     a.flags = flags;
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
                        (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
                        (double4*)a.node2);
     if (a.n3 > 0) hipLaunchKernelGGL(rtus_node3_kernel, dim3((a.n3 + 63) / 64), dim3(64), 0, s, a.node2, a.n2, (double4*)a.node3, a.n3);
+    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.node3, a.n0, a.n1,
+                       a.n2, a.n3, (TreeNode*)a.tree);
     const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
     if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_shoot_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rtus_shoot_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, a);
@@ -814,17 +872,9 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     ShootArgs& a = q.s;
     a.k = make_lens_k(lens);
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f_scratch;
-    a.curve = (const double2*)w;
-    a.phi_s = (const double*)(w + ws_phis_off(n));
-    a.tan_u = (const double2*)(w + ws_tanu_off(n));
-    a.node0 = (const double4*)(w + ws_node0_off(n));
-    a.node1 = (const double4*)(w + ws_node1_off(n));
-    a.node2 = (const double4*)(w + ws_node2_off(n));
-    a.node3 = (const double4*)(w + ws_node3_off(n));
+    shoot_args_workspace(a, w, n);
     a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr;
-    a.n = n; a.n_tx = n_tx; a.n_geom = n_geom;
-    a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
-    a.n3 = a.n2 > 8 ? (n + 4095) / 4096 : 0;
+    a.n_tx = n_tx; a.n_geom = n_geom;
     a.flags = flags;
     q.alpha = alpha; q.land_x = land; q.land_box = boxes; q.nb = nb; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
