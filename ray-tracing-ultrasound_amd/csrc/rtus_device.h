@@ -54,10 +54,10 @@ __device__ __forceinline__ void lens_eval_sc(const LensK& k, double s, double c,
                                              double& dz, double& dx)
 {
     double B = k.phi_3 * c - k.twoTc;              // 2 d cos(a) - 2 T c1^2/c2
-    double sq = sqrt(B * B - k.C4A);
-    double h = (-B - sq) / k.twoA;
+    double sq = rtus_sqrt(B * B - k.C4A);
+    double h = rtus_div(-B - sq, k.twoA);
     double dB = -k.phi_3 * s;
-    double dS = (1.0 / (2.0 * sq)) * (2.0 * B * dB);
+    double dS = rtus_div(1.0, 2.0 * sq) * (2.0 * B * dB);
     double dh = k.phi_1 * (dB + dS);
     x = h * s;
     z = h * c;
@@ -84,7 +84,7 @@ __device__ __forceinline__ double refract_angle(double phi_in, double phi_slope,
 __device__ __forceinline__ double dist2d(double x1, double z1, double x2, double z2)
 {
     double dx = x1 - x2, dz = z1 - z2;             // main_rt.py:444-445
-    return sqrt(dx * dx + dz * dz);
+    return rtus_sqrt(dx * dx + dz * dz);
 }
 
 // np.isclose(a, b, rtol, atol) for scalars, equal_nan=False.

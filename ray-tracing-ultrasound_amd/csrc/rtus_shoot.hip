@@ -276,10 +276,10 @@ __device__ __forceinline__ double rsqrt_fast(double x)
     const double e = fma(-x * y, y, 1.0);
     return fma(y * e, fma(e, 0.375, 0.5), y);   // cubic step: 5e-8 -> rounding level; x <= 0 -> NaN
 }
-template <bool FAST> __device__ __forceinline__ double m_div(double a, double b) { return FAST ? a * rcp_fast(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ double m_div(double a, double b) { return FAST ? a * rcp_fast(b) : rtus_div(a, b); }
 template <bool FAST> __device__ __forceinline__ double m_sqrt(double x)
 {
-    if (!FAST) return sqrt(x);
+    if (!FAST) return rtus_sqrt(x);
     const double r = x * rsqrt_fast(x);
     return x == 0.0 ? 0.0 : r;                  // keeps sqrt(0) = 0 (tangent hits, grazing refraction)
 }
@@ -288,7 +288,7 @@ template <bool FAST> __device__ __forceinline__ double m_sqrt(double x)
 template <bool FAST> __device__ __forceinline__ double seg_time(double x1, double z1, double x2, double z2, double c,
                                                                  double inv_c)
 {
-    if (!FAST) return dist2d(x1, z1, x2, z2) / c;
+    if (!FAST) return rtus_div(dist2d(x1, z1, x2, z2), c);
     const double dx = x1 - x2, dz = z1 - z2;
     return m_sqrt<true>(dx * dx + dz * dz) * inv_c;
 }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // RTUS_TRUE_PIPE_TANGENT (not the reference): tangent of the circle where it actually is
     const double xt = (a.flags & RTUS_TRUE_PIPE_TANGENT) ? xq - off : xq;
     const double slope = FAST ? -xt * rsqrt_fast(r_outer * r_outer - xt * xt)
-                              : -xt / sqrt(r_outer * r_outer - xt * xt);   // :237-238
+                              : rtus_div(-xt, rtus_sqrt(r_outer * r_outer - xt * xt));   // :237-238
     double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
     if (!FAST) {
         const double phi_sl = rtus_atan(slope);                        // :287
@@ -532,9 +532,9 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     double a3;
     if (!FAST) {
         // :396-397 alpha_i = atan2(x_i, z_i) is only ever used through its sine and cosine: x_i / rho, z_i / rho
-        const double rho = sqrt(xi * xi + zi * zi);
+        const double rho = rtus_sqrt(xi * xi + zi * zi);
         double lx, lz, ldz, ldx;
-        lens_eval_sc(k, xi / rho, zi / rho, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
+        lens_eval_sc(k, rtus_div(xi, rho), rtus_div(zi, rho), lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
         const double phi_last = refract_angle(phi_l, rtus_atan2(ldz, ldx), k.eta12);   // :398
         a3 = rtus_tan(phi_last);                                       // :401
     } else {

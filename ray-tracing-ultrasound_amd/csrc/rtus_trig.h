@@ -62,7 +62,10 @@ static const RtusTrigTable rtus_k_host = {RTUS_TRIG_TABLE(X)};
 // (the pointer carries the constant address space: a uniform load through a plain pointer is only a scalar load while the
 // compiler can prove nothing in the kernel writes there, and it cannot once the pointer went through the asm)
 typedef const RtusTrigTable __attribute__((address_space(4)))* rtus_ktab_ptr;
-#define RTUS_KTAB rtus_ktab_ptr ktab_ = (rtus_ktab_ptr)(uintptr_t)&rtus_k_dev; asm("" : "+s"(ktab_))
+// (a __device__-only accessor: a static device variable named inside a __host__ __device__ function is made an external
+// symbol, and every use then loads its address from the GOT)
+__device__ __forceinline__ rtus_ktab_ptr rtus_ktab_addr() { return (rtus_ktab_ptr)(uintptr_t)&rtus_k_dev; }
+#define RTUS_KTAB rtus_ktab_ptr ktab_ = rtus_ktab_addr(); asm("" : "+s"(ktab_))
 #define RTUS_K(name) (ktab_->name)
 #else
 #define RTUS_KTAB
@@ -85,6 +88,45 @@ __device__ __forceinline__ double rtus_fma_s(double x, double acc, double c)
 
 RTUS_HD uint64_t rtus_bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 RTUS_HD double rtus_from_bits(uint64_t u) { double v; memcpy(&v, &u, 8); return v; }
+
+// a / b, correctly rounded: the compiler's own fp64 division sequence (v_rcp_f64, two Newton steps on the reciprocal, the
+// quotient and one correction, v_div_fixup for zero / infinite / NaN operands) WITHOUT its two v_div_scale_f64 and the
+// scaling half of v_div_fmas_f64.  Those only act when an exponent is extreme (a denormal or > 2^1000 denominator, or a
+// quotient about to leave the normal range); everywhere else they pass their operands through, so the result is the same
+// bits.  The trace divides lengths, slopes (<= 1.7e16) and sines.  Two VALU slots fewer per division, and no VCC traffic.
+RTUS_HD double rtus_div(double a, double b)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    double q = a * r;
+    q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
+    return __builtin_amdgcn_div_fixup(q, b, a);
+#else
+    return a / b;
+#endif
+}
+
+// sqrt(x), correctly rounded: likewise the compiler's own sequence (v_rsq_f64, one coupled Newton step on (g, h) = (sqrt x,
+// 1 / 2 sqrt x), two residual corrections, x itself for +-0 and +inf) without the 2^256 pre-scaling it applies to x < 2^-767
+// (two v_ldexp_f64, a compare and two selects per call).  Same bits for every x >= 2^-767; the trace's radicands are
+// squared lengths and discriminants of them (an exact 0 — a tangent hit — takes the x = 0 branch).
+RTUS_HD double rtus_sqrt(double x)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;        // +-0, +inf
+#else
+    return sqrt(x);
+#endif
+}
 
 // x = n pi/2 + (r + t), |r| <= pi/4 (+ rounding), t the tail of r.  fdlibm __ieee754_rem_pio2, medium branch,
 // always with the second pair of constants: pi/2 = p1 + p2 + p2t to 118 bits; n p1 and n p2 are exact for |n| < 2^20.
@@ -188,7 +230,7 @@ RTUS_HD double rtus_tan(double x, bool& steep)
     const uint32_t odd = (uint32_t)-(n & 1);
     steep = (n & 1) && fabs(r) < (1.0 / 300.0);
     const double num = rtus_bitsel(odd, -c, s), den = rtus_bitsel(odd, s, c);
-    return num / den;
+    return rtus_div(num, den);
 }
 RTUS_HD double rtus_tan(double x) { bool steep; return rtus_tan(x, steep); }
 
@@ -292,7 +334,7 @@ RTUS_HD double rtus_asin_R(double t)
     q = RTUS_FMA_K(t, q, qS2);
     q = RTUS_FMA_K(t, q, qS1);
     q = fma(t, q, 1.0);
-    return p / q;
+    return rtus_div(p, q);
 }
 RTUS_HD double rtus_asin_small(double x) { return fma(x, rtus_asin_R(x * x), x); }       // |x| < 0.5
 RTUS_HD double rtus_asin_big(double x)                                                   // |x| >= 0.5 (> 1: NaN)
