@@ -8,8 +8,8 @@
 //   node0   double4[n/8]      bounding box (xc, xh, zc, zh = centre / half-extent) of 8 polyline points
 //   node1   double4[n/64]     ... of 64 points
 //   node2   double4[n/512]    ... of 512 points
-//   node3   double4[n/4096]   ... of 4096 points (long polylines only)
-//   tree    TreeNode[n0+n1+n2+n3]  the same boxes in depth-first order with skip links (what the crossing search walks)
+//   tree    TreeNode[n0+n1+n2+n3+1]  the same boxes (+ 4096-point boxes on long polylines) in depth-first order with
+//                             skip links: what the crossing search walks
 //   out8    [n_geom][n_tx][8][n]   SoA per (geometry, tx): every store is a coalesced 512-B row
 //
 // Crossing search (reference find_line_curve_intersection, main_rt.py:78-99: FIRST index j with
@@ -37,14 +37,13 @@ struct ShootArgs {
     const double4* __restrict__ node0;  // [n0]
     const double4* __restrict__ node1;  // [n1]
     const double4* __restrict__ node2;  // [n2]
-    const double4* __restrict__ node3;  // [n3] 4096-point boxes, only built when n2 > 8 (else n3 = 0)
     const struct TreeNode* __restrict__ tree;   // [n0 + n1 + n2 + n3] the boxes in depth-first order (see TreeNode)
     double* __restrict__ out8;          // nullable
     double* __restrict__ tof4;          // nullable
     double* __restrict__ tof;           // nullable
     double* __restrict__ land_x;        // nullable
     uint8_t* __restrict__ status;       // nullable
-    int n, n_tx, n_geom, n0, n1, n2, n3, n_tree;
+    int n, n_tx, n_geom, n0, n1, n2, n3, n_tree;    // n3: 4096-point boxes, only when n2 > 8 (else 0); they live in the tree only
     unsigned flags;
 };
 
@@ -102,20 +101,6 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
     }
 }
 
-// 4096-point boxes from eight 512-point boxes (long polylines only).
-__global__ void rtus_node3_kernel(const double4* __restrict__ node2, int n2, double4* __restrict__ node3, int n3)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n3) return;
-    double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
-    for (int j = i * 8; j < min(i * 8 + 8, n2); ++j) {
-        const double4 b = node2[j];
-        xmin = fmin(xmin, b.x - b.y); xmax = fmax(xmax, b.x + b.y);
-        zmin = fmin(zmin, b.z - b.w); zmax = fmax(zmax, b.z + b.w);
-    }
-    node3[i] = make_box(xmin, xmax, zmin, zmax);
-}
-
 // The box hierarchy in depth-first (pre-order) order, one 64-byte record per box: what the crossing search walks.  A visit
 // is ONE scalar load at a wave-uniform index i; the next index is i + 1 (first child / next leaf) while some ray is
 // still undecided about this box and `skip` (the record after this box's whole subtree) once every ray is decided — a
@@ -137,8 +122,8 @@ struct __attribute__((aligned(64))) TreeNode {
 // part of the certification margin).
 
 __global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double4* __restrict__ node1,
-                                 const double4* __restrict__ node2, const double4* __restrict__ node3,
-                                 int n0, int n1, int n2, int n3, TreeNode* __restrict__ tree)
+                                 const double4* __restrict__ node2, int n0, int n1, int n2, int n3,
+                                 TreeNode* __restrict__ tree)
 {
     const int total = n0 + n1 + n2 + n3;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,12 +133,22 @@ __global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double
     if (id < n0) { L = 0; k = id; src = node0; }
     else if (id < n0 + n1) { L = 1; k = id - n0; src = node1; }
     else if (id < n0 + n1 + n2) { L = 2; k = id - n0 - n1; src = node2; }
-    else { L = 3; k = id - n0 - n1 - n2; src = node3; }
+    else { L = 3; k = id - n0 - n1 - n2; src = nullptr; }
     const int top = n3 > 0 ? 3 : 2;
     const int sz[4] = {1, 9, 73, 585};
     int pos = (k >> (3 * (top - L))) * sz[top];
     for (int l = top - 1; l >= L; --l) pos += 1 + ((k >> (3 * (l - L))) & 7) * sz[l];
-    const double4 b = src[k];
+    double4 b;
+    if (L < 3) b = src[k];
+    else {                              // a 4096-point box (long polylines only): the union of eight 512-point boxes
+        double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+        for (int j = k * 8; j < min(k * 8 + 8, n2); ++j) {
+            const double4 c = node2[j];
+            xmin = fmin(xmin, c.x - c.y); xmax = fmax(xmax, c.x + c.y);
+            zmin = fmin(zmin, c.z - c.w); zmax = fmax(zmax, c.z + c.w);
+        }
+        b = make_box(xmin, xmax, zmin, zmax);
+    }
     TreeNode t;
     t.xc = b.x; t.xh = b.y; t.zc = b.z; t.zh = b.w;
     t.j0 = k << (3 * (L + 1)); t.j1 = t.j0 + (8 << (3 * L));
@@ -759,9 +754,8 @@ static size_t ws_tanu_off(int n) { return align32(ws_phis_off(n) + (size_t)n * s
 static size_t ws_node0_off(int n) { return align32(ws_tanu_off(n) + (size_t)n * sizeof(double2)); }
 static size_t ws_node1_off(int n) { return ws_node0_off(n) + (size_t)((n + 7) / 8) * sizeof(double4); }
 static size_t ws_node2_off(int n) { return ws_node1_off(n) + (size_t)((n + 63) / 64) * sizeof(double4); }
-static size_t ws_node3_off(int n) { return ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4); }
 static int n_tree_nodes(int n) { return (n + 7) / 8 + (n + 63) / 64 + (n + 511) / 512 + (n + 4095) / 4096 + 1; }   // upper bound (node3 may be unused) + the extent record
-static size_t ws_tree_off(int n) { return (ws_node3_off(n) + (size_t)((n + 4095) / 4096) * sizeof(double4) + 63) & ~(size_t)63; }
+static size_t ws_tree_off(int n) { return (ws_node2_off(n) + (size_t)((n + 511) / 512) * sizeof(double4) + 63) & ~(size_t)63; }
 size_t rtus_ws_bytes(int n) { return ws_tree_off(n) + (size_t)n_tree_nodes(n) * sizeof(TreeNode); }
 
 // Workspace pointers and sizes of a ShootArgs (the workspace base must be 64-byte aligned: hipMalloc gives 256).
@@ -773,7 +767,6 @@ static void shoot_args_workspace(ShootArgs& a, char* w, int n)
     a.node0 = (const double4*)(w + ws_node0_off(n));
     a.node1 = (const double4*)(w + ws_node1_off(n));
     a.node2 = (const double4*)(w + ws_node2_off(n));
-    a.node3 = (const double4*)(w + ws_node3_off(n));
     a.tree = (const TreeNode*)(w + ws_tree_off(n));
     a.n = n;
     a.n0 = (n + 7) / 8; a.n1 = (n + 63) / 64; a.n2 = (n + 511) / 512;
@@ -797,9 +790,8 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
                        (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
                        (double4*)a.node2);
-    if (a.n3 > 0) hipLaunchKernelGGL(rtus_node3_kernel, dim3((a.n3 + 63) / 64), dim3(64), 0, s, a.node2, a.n2, (double4*)a.node3, a.n3);
-    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.node3, a.n0, a.n1,
-                       a.n2, a.n3, (TreeNode*)a.tree);
+    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
+                       a.n3, (TreeNode*)a.tree);
     const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
     if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_shoot_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rtus_shoot_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, a);

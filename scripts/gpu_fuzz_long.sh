@@ -4,9 +4,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/fuzz; mkdir -p "$OUT"
 cd $ROOT
 rc=0
-for spec in "900 12345" "600 2"; do
+for spec in "400 12345" "150 2"; do
   set -- $spec
-  timeout -k 10 1000 python3 scripts/fuzz_shoot.py $1 $2 > $OUT/long_$2.txt 2>&1 || rc=1
+  timeout -k 10 880 python3 scripts/fuzz_shoot.py $1 $2 > $OUT/long_$2.txt 2>&1 || rc=1
   tail -2 $OUT/long_$2.txt
 done
 exit $rc
