@@ -14,6 +14,7 @@ B=$ROOT/bench.py
 PMC="--steps 5 --warmup 2 --graph off --no-extra --no-cpu-baseline"       # headline workload (cfg3_planar), eager launches
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 SQ2="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"
+SQSH="SQ_INSTS_SMEM SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_RD SQ_INSTS_VALU_INT32"
 SQ3="SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 echo "[1] un-profiled bench lines: the driver's K (20 / 5) and the default K"
 python3 $B --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
@@ -35,6 +36,7 @@ echo "[6] forward trace: one size per run (reference geometry 1024 tx x 8192 ray
 for mode in 0 1; do
   rocprofv3 --kernel-trace --stats -d $OUT/kt_shoot$mode -o kt --output-format csv -- python3 $ROOT/scripts/run_shoot_once.py $mode > $OUT/kt_shoot$mode.log 2>&1
   rocprofv3 --pmc $SQ -d $OUT/sq_shoot$mode -o sq --output-format csv -- python3 $ROOT/scripts/run_shoot_once.py $mode > $OUT/sq_shoot$mode.log 2>&1
+  rocprofv3 --pmc $SQSH -d $OUT/sq_shoot${mode}b -o sq --output-format csv -- python3 $ROOT/scripts/run_shoot_once.py $mode > $OUT/sq_shoot${mode}b.log 2>&1
 done
 rocprofv3 --kernel-trace --stats -d $OUT/kt_sweep -o kt --output-format csv -- python3 $B --workload ref_sweep --steps 50 --warmup 5 --graph off --no-extra --no-cpu-baseline > $OUT/kt_sweep.log 2>&1
 echo "[7] consumers: traffic of the TFM gather kernel and of the focal-law stream"
@@ -45,4 +47,5 @@ echo "[8] instruction issue costs"
 $ROOT/scripts/ubench_issue > $OUT/ubench_issue.txt 2>&1
 $ROOT/scripts/ubench_issue2 > $OUT/ubench_issue2.txt 2>&1
 $ROOT/scripts/ubench_issue3 > $OUT/ubench_issue3.txt 2>&1
+$ROOT/scripts/ubench_issue4 > $OUT/ubench_issue4.txt 2>&1
 find $OUT -name "*.csv" | wc -l

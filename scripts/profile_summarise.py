@@ -159,15 +159,16 @@ shoot = (kernel_rows("kt_shoot0", "reference geometry 1024 tx x 8192 rays, refer
          kernel_rows("kt_sweep", "the reference's own sweep, 210 geometries x 905 rays (bench.py --workload ref_sweep --graph off)"))
 write_rows(os.path.join(dst, f"{tag}_shoot_kernel_rows.csv"), shoot)
 for mode, name in ((0, "compat"), (1, "fast")):
-    t, m = counters([f"sq_shoot{mode}"], "rtus_shoot_kernel")
+    t, m = counters([f"sq_shoot{mode}", f"sq_shoot{mode}b"], "rtus_shoot_kernel")
     write_counters(os.path.join(dst, f"{tag}_pmc_shoot_refscale_sq_{name}.csv"), t, m)
     for k, cs in t.items():
-        print(f"shoot {name}: VALU/wave {cs['SQ_INSTS_VALU'] / cs['SQ_WAVES']:.0f}  SALU/wave {cs['SQ_INSTS_SALU'] / cs['SQ_WAVES']:.0f}")
+        print(f"shoot {name}: VALU/wave {cs['SQ_INSTS_VALU'] / cs['SQ_WAVES']:.0f}  SALU/wave {cs['SQ_INSTS_SALU'] / cs['SQ_WAVES']:.0f}  "
+              f"SMEM/wave {cs.get('SQ_INSTS_SMEM', 0) / cs['SQ_WAVES']:.0f}")
 write_rows(os.path.join(dst, f"{tag}_consumers_kernel_rows.csv"), kernel_rows("kt_cons", "scripts/run_consumers_once.py"))
 
 # ---- instruction issue costs ----------------------------------------------------------------------------------------
 with open(os.path.join(dst, f"{tag}_ubench_issue.txt"), "w") as fh:
-    for n in ("ubench_issue", "ubench_issue2", "ubench_issue3"):
+    for n in ("ubench_issue", "ubench_issue2", "ubench_issue3", "ubench_issue4"):
         fh.write(f"==== scripts/{n}.hip ====\n" + open(os.path.join(src, n + ".txt")).read() + "\n")
 
 print("headline kernel:", hk, "| kernel-trace avg ns", head["avg_ns"], "median", head["median_ns"], "calls", head["calls"])
