@@ -186,10 +186,9 @@ struct Walk {
     // reads d > 0 (multiplying by +-1 is exact: every certification decision is the one the unsigned form makes)
     double ms, bs, sg, am;
     double marg;             // certification margin; +inf for rays with d_0 == 0 exactly (class 0 is never certified)
-    int slot;                // per lane: first point of the box where the lane left the walk — found there, or parked on that leaf
+    int slot;                // per lane: first point of the box where the lane left the walk (its answer lies in slot .. slot + 7)
     int start;               // per lane: polyline points before this index are known to have class c0
     lanemask active;         // rays still walking
-    lanemask pend;           // rays parked on the leaf `slot`
 };
 
 // this lane's bit of a wave-uniform mask: the mask itself becomes the v_cndmask / exec operand (no per-lane shift + compare)
@@ -230,6 +229,55 @@ __device__ __forceinline__ TreeNode load_record(const TreeNode* __restrict__ bas
     return __builtin_bit_cast(TreeNode, r);
 }
 
+// The first pass of the walk (nearly always the only one), written out: the loop below is walk_pass<false> instruction for
+// instruction, with the scalar bookkeeping the way the hardware offers it — the mask instructions set SCC themselves, so
+// "does the wave descend" and "is any ray left" cost no compare, and the two exits are two branches.  12 scalar
+// instructions per box; the compiler's version of the same C++ has 20 (compares re-materialised as 64-bit selects,
+// register copies for the loop-carried masks), and the scalar ALU issues one instruction per ~4.4 cycles per SIMD, so
+// those eight are ~10 % of the kernel.  Fixed scalar registers (s75-s79, s84-s99) because an asm operand cannot name the
+// halves of a 16-register load.  No hardware hazard in here needs a manual wait state (gfx9 list: VALU-written SGPR / VCC
+// read by the scalar ALU and VCC written by the scalar ALU read by v_cndmask are interlocked); the order of the dependent
+// pairs is the one the compiler emits for the C++ form.  Record layout: see TreeNode.
+__device__ __forceinline__ void walk_first_pass(Walk& W, const TreeNode* __restrict__ tree, int n_tree)
+{
+    const unsigned end = (unsigned)n_tree * (unsigned)sizeof(TreeNode);
+    lanemask active = W.active;
+    unsigned off = 0;
+    int slot = W.slot, tmp;
+    double e, sm;
+    asm("s_cmp_eq_u64 %[act], 0\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"
+        "s_load_dwordx16 s[84:99], %[base], %[off]\n\t"
+        "s_add_u32 s75, %[off], 64\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_fma_f64 %[e], s[84:85], %[ms], %[bs]\n\t"           // ms xc + bs
+        "v_add_f64 %[sm], %[marg], s[90:91]\n\t"               // zh + margin
+        "v_fma_f64 %[e], %[sg], s[88:89], -%[e]\n\t"           // e = sg zc - (ms xc + bs): sg d at the box centre
+        "v_fma_f64 %[sm], %[am], s[86:87], %[sm]\n\t"          // s = |m| xh + zh + margin
+        "v_cmp_gt_f64_e32 vcc, %[e], %[sm]\n\t"                // pos: the whole box keeps the class of point 0
+        "v_cmp_lt_f64_e64 s[78:79], %[e], -%[sm]\n\t"          // neg: the whole box has the opposite class
+        "s_andn2_b64 s[76:77], %[act], vcc\n\t"                // np = active & ~pos
+        "s_or_b64 s[78:79], s[78:79], s[94:95]\n\t"            // neg | leafm
+        "s_and_b64 vcc, s[76:77], s[78:79]\n\t"                // gone = np & (neg | leafm)
+        "s_max_u32 s93, s93, s75\n\t"                          // the walk advances whatever the record holds
+        "s_andn2_b64 s[76:77], s[76:77], s[78:79]\n\t"         // undecided rays of an inner box; SCC = any
+        "s_cselect_b32 %[off], s75, s93\n\t"                   // descend: next record; else: past this subtree
+        "v_mov_b32_e32 %[tmp], s92\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"                  // active &= ~gone; SCC = any ray left
+        "v_cndmask_b32_e32 %[slot], %[slot], %[tmp], vcc\n\t"  // rays that leave here remember the box's first point
+        "s_cbranch_scc0 2f\n\t"
+        "s_cmp_lt_u32 %[off], %[end]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [act] "+s"(active), [off] "+s"(off), [slot] "+v"(slot), [tmp] "=&v"(tmp), [e] "=&v"(e), [sm] "=&v"(sm)
+        : [base] "s"(tree), [end] "s"(end), [ms] "v"(W.ms), [bs] "v"(W.bs), [sg] "v"(W.sg), [am] "v"(W.am), [marg] "v"(W.marg)
+        : "vcc", "scc", "s75", "s76", "s77", "s78", "s79", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+          "s94", "s95", "s96", "s97", "s98", "s99");
+    W.active = active;
+    W.slot = slot;
+}
+
 template <bool RETRY>
 __device__ __forceinline__ void walk_pass(Walk& W, const TreeNode* __restrict__ tree, int n_tree)
 {
@@ -241,11 +289,12 @@ __device__ __forceinline__ void walk_pass(Walk& W, const TreeNode* __restrict__ 
         lanemask pos, neg;
         certify(W, make_double4(nd.xc, nd.xh, nd.zc, nd.zh), W.marg, pos, neg);
         if (RETRY) known_prefix(W, nd.j0, nd.j1, pos, neg);
-        // inner box: rays certified "opposite" are found here (p = j0), the wave descends if some ray is undecided;
-        // leaf: every ray not certified "same" leaves — found, or parked on the leaf.  One formula, leafm = all / none:
+        // inner box: rays certified "opposite" leave here (their answer is its first point), the wave descends if some
+        // ray is undecided; leaf: every ray not certified "same" leaves.  One formula, leafm = all / none.  A ray that
+        // leaves looks at the 8 points from j0 on by itself afterwards — for a certified ray the first of them differs,
+        // so "found here" and "parked on this leaf" need no separate bookkeeping.
         const lanemask np = W.active & ~pos, und = np & ~neg;
         const lanemask gone = np & (neg | nd.leafm);
-        W.pend |= und & nd.leafm;
         W.active &= ~gone;
         W.slot = lane_bit(gone) ? nd.j0 : W.slot;
         const unsigned next = off + (unsigned)sizeof(TreeNode);
@@ -401,7 +450,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     W.sg = lane_bit(c0neg) ? -1.0 : 1.0;
     W.ms = W.sg * m; W.bs = W.sg * b; W.am = fabs(m);
     W.marg = lane_bit(c0zero) ? INFINITY : marg0;
-    W.slot = 0; W.start = 0; W.pend = 0;
+    W.slot = 0; W.start = 0;
     W.active = __ballot(fin);                       // non-finite lines: nothing to find
     int idx = -1;                                   // p - 1 (segment idx .. idx+1 holds the first sign change), -1 if none
     // Lock-step part: boxes are visited in index order with wave-uniform indices (scalar loads); a ray
@@ -410,16 +459,20 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // union of all 64 rays' leaves point by point.
     for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
         const lanemask active0 = W.active;
+#ifdef RTUS_WALK_CXX   // the same pass from the C++ template (for comparison builds)
         if (pass == 0) walk_pass<false>(W, a.tree, a.n_tree); else walk_pass<true>(W, a.tree, a.n_tree);
-        // rays a box answered during this pass: p = first point of that box.  Rays still active walked off the
-        // end: no class change anywhere, idx stays -1.
-        idx = lane_bit(active0 & ~W.active & ~W.pend) ? W.slot - 1 : idx;
+#else
+        if (pass == 0) walk_first_pass(W, a.tree, a.n_tree); else walk_pass<true>(W, a.tree, a.n_tree);
+#endif
+        // Rays still active walked off the end: no class change anywhere, idx stays -1.  Every ray that left the walk
+        // did so at a box whose first 8 points hold its answer.
+        const lanemask left = active0 & ~W.active;
         W.active = 0;
-        if (!W.pend) break;
+        if (!left) break;
         DBG(3);
         // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
         // point: a copy never changes class, so the padding cannot produce a hit).
-        const bool mine = lane_bit(W.pend);
+        const bool mine = lane_bit(left);
         const double2* __restrict__ cp = a.curve + W.slot;
         double2 c[8];
 #pragma unroll
@@ -444,7 +497,6 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         idx = got ? W.slot + hit - 1 : idx;
         W.start = (mine && !got) ? W.slot + 8 : W.start;             // nothing here: resume after this leaf
         W.active = __ballot(mine && !got);
-        W.pend = 0;
         if (!W.active) break;
     }
 
@@ -784,6 +836,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     a.k = make_lens_k(lens);
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f;
     shoot_args_workspace(a, w, n);
+    if ((unsigned long long)a.n_tree * sizeof(TreeNode) >= 0xffffffffull) return hipErrorInvalidValue;   // the walk's record offsets are 32-bit
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
     a.n_tx = n_tx; a.n_geom = n_geom;
     a.flags = flags;
