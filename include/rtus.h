@@ -39,7 +39,7 @@ typedef enum rtus_status {
     RTUS_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad flag (reference: ValueError main_rt.py:24-29) */
     RTUS_ERR_NO_DEVICE = -2,     /* no HIP device / device index out of range */
     RTUS_ERR_HIP = -3,           /* a HIP runtime call failed; rtus_last_hip_error() has the code */
-    RTUS_ERR_WORKSPACE = -4,     /* workspace pointer null or too small */
+    RTUS_ERR_WORKSPACE = -4,     /* workspace pointer null, not 64-byte aligned, or too small */
     RTUS_ERR_UNSUPPORTED = -5    /* e.g. more layers than RTUS_MAX_LAYERS */
 } rtus_status;
 
@@ -105,6 +105,8 @@ int rtus_release(int device);
 #define RTUS_TRUE_PIPE_TANGENT 0x2u
 #define RTUS_ANALYTIC_LENS 0x4u
 
+/* Device scratch of one call (polyline, tangents, bounding boxes and their depth-first records): 64-byte aligned
+ * (hipMalloc gives 256), rebuilt by every call, not shared between calls that may run concurrently. */
 size_t rtus_shoot_workspace_bytes(int n_rays);
 
 int rtus_shoot_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,

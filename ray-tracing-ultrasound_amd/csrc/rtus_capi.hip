@@ -263,7 +263,7 @@ int rtus_shoot_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, con
     int st = check_shoot(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays);
     if (st) return st;
     if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
-    if (!d_workspace || workspace_bytes < rtus_ws_bytes(n_rays)) return RTUS_ERR_WORKSPACE;
+    if (!d_workspace || ((uintptr_t)d_workspace & 63) || workspace_bytes < rtus_ws_bytes(n_rays)) return RTUS_ERR_WORKSPACE;
     LAUNCH_TRY(rtus_launch_shoot(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_out8,
                               d_tof4, d_tof, d_land_x, d_status, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;
@@ -331,7 +331,7 @@ int rtus_solve_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, con
 {
     int st = check_solve(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt, flags);
     if (st) return st;
-    if (!d_workspace || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx)) return RTUS_ERR_WORKSPACE;
+    if (!d_workspace || ((uintptr_t)d_workspace & 63) || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx)) return RTUS_ERR_WORKSPACE;
     LAUNCH_TRY(rtus_launch_solve(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt,
                               d_alpha_root, d_tt_all, d_alpha_all, d_n_roots, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;

@@ -16,7 +16,7 @@
 // sign(d_j) != sign(d_{j+1}), d_j = z_p[j] - (m x_p[j] + b)).  The reference scans all n points
 // per ray (90 % of its run time).  Here a wave scans in lock-step: the polyline index is
 // wave-uniform, so polyline points and boxes arrive by scalar loads (SGPRs, broadcast for free)
-// and each lane only evaluates its own line.  A box (512 -> 64 -> 8 points) is skipped when EVERY
+// and each lane only evaluates its own line.  A box (4096 -> 512 -> 64 -> 8 points) is skipped when EVERY
 // lane's line is provably on one side of it by more than a rounding margin; otherwise the wave
 // descends, and only 8-point leaves are evaluated point by point.  Skipping cannot change which
 // index is found — it only avoids evaluating points whose sign is already certain — so the result
@@ -350,10 +350,11 @@ __device__ __forceinline__ double cap_vertical(double ux, double uz)
 struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };
 struct RayOut { double xq, zq, xi, zi, x_in; };
 
-// Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan
-// through the bounded-range kernels of rtus_trig.h and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho
-// (no angle formed): 1,6xx instead of 2,066 executed VALU instructions per wave.  ONE place keeps the library's sin and
-// tan: the first refraction of a wave that holds a near-vertical refracted line (|a_pq| > 300: ~1 % of the waves).  The
+// Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan /
+// atan2 / atan / asin through the kernels of rtus_trig.h, correctly rounded division and square root (rtus_div,
+// rtus_sqrt) and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho (no angle formed): 1,212 instead
+// of 2,066 executed VALU instructions per wave.  ONE place keeps the library's routines: the first refraction of a wave
+// that holds a near-vertical refracted line (|a_pq| > 300: ~1 % of the waves).  The
 // reference intersects that line with the pipe through the quadratic formula in slope-intercept form
 // (main_rt.py:349-364), which amplifies a last-bit difference of the angle by ~|a_pq|^3 — bit-level agreement with its
 // libm decides the pipe point there, nowhere else (measured on 2.5 M random rays, the oracle with either trigonometry:
