@@ -109,12 +109,12 @@ template <typename R> __device__ __forceinline__ LensConst<R> lens_const(const L
 
 // T(alpha), g = dT/dalpha and (WITH_GP) g' for one (A, F).  Without g' the second derivatives h'', P'' are skipped:
 // about a quarter of the arithmetic.
-template <typename R, bool WITH_GP>
+template <typename R, bool WITH_GP, bool POLY>
 __device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, R za, R xf, R zf, R& T, R& g,
                                           R& gp)
 {
     R s, c;
-    if (k.poly_trig) sincos_poly<R>(alpha, s, c);           // wave-uniform
+    if (POLY) sincos_poly<R>(alpha, s, c);                  // [a_lo, a_hi] inside +-1 rad: chosen at launch
     else sincos_r<R>(alpha, &s, &c);
     const R B = k.phi_3 * c - k.twoTc;                      // main_rt.py:184
     const R B1 = -k.phi_3 * s, B2 = -k.phi_3 * c;           // B', B''
@@ -142,6 +142,20 @@ __device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, 
 }
 
 typedef unsigned int lens_u32x2 __attribute__((ext_vector_type(2)));
+// Stores through ONE descriptor per workgroup: its base is the workgroup's first output row, its extent one row, so the
+// hardware's range check on the per-lane offset drops the lanes past the last target; the row of the current element
+// enters as the instruction's scalar offset (not range-checked; + one s_add per element instead of rebuilding a
+// descriptor from a 64-bit row pointer).
+template <typename R> __device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, R v);
+template <> __device__ __forceinline__ void store_at<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void store_at<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, double v)
+{
+    const lens_u32x2 bits = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(bits, rs, voff, soff, 0);
+}
 template <typename R> __device__ __forceinline__ void store_row(R* row, unsigned n_f, unsigned f, R v);
 template <> __device__ __forceinline__ void store_row<float>(float* row, unsigned n_f, unsigned f, float v)
 {
@@ -160,14 +174,16 @@ template <typename R> struct __attribute__((aligned(16))) LensRec {
     R xa, za;
     float w1, w3;            // Lagrange weights of the newest / oldest of the three previous solutions (w2 = 1 - w1 - w3)
     int mode;                // 0: no history, 1: previous alpha, 2: extrapolate
-    int pad;
+    int run;                 // number of consecutive mode-2 elements from this one on (inside the workgroup's block)
 };
 
 // A workgroup = 256 targets x `eb` consecutive elements.  The minimiser alpha*(element) is smooth in the element
 // position, so the three previous solutions extrapolate the next start (Lagrange weights from the element
 // positions, worked out once per workgroup by thread t for element e0 + t and parked in LDS, as in
 // rtus_fermat.hip): from the third element of a block on, Newton starts ~1e-7 rad from the root.
-template <typename R>
+// POLY: sin / cos by polynomial (search interval inside +-1 rad); WA: the minimising alpha is written too.  Both are
+// launch-time facts: as template parameters they leave no wave-uniform branches in the element loop.
+template <typename R, bool POLY, bool WA>
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> a)
 {
     __shared__ LensRec<R> rec[64];
@@ -197,7 +213,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         r.w1 = quad ? q1 : (lin ? t2 * r12 : 0.0f);
         r.w3 = quad ? q3 : 0.0f;
         r.mode = lin ? 2 : (hist >= 1 ? 1 : 0);
-        r.pad = 0;
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(r.mode == 2 && lane < ne);
+        const unsigned long long rest = ~(m2 >> lane);
+        r.run = (r.mode == 2 && lane < ne) ? (rest ? __ffsll((long long)rest) - 1 : 64 - lane) : 0;
         rec[lane] = r;
     }
     __syncthreads();
@@ -214,41 +232,37 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     const R tolT = sizeof(R) == 4 ? R(2e-12) : R(1e-21);
 
     R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements
-    R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation ...
-    bool rgp_ok = false;                                    // ... usable if that solve ended at an interior minimum
-    R* row = a.tt + (size_t)e0 * a.n_f;                     // output row of the current element (wave-uniform)
-    R* arow = a.alpha_out ? a.alpha_out + (size_t)e0 * a.n_f : nullptr;
-    for (int li = 0; li < ne; ++li) {
-        const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
-        const R xa = rec[li].xa, za = rec[li].za;
-        R alpha;
-        if (mode == 2) {                                    // wave-uniform
-            const float w1 = rec[li].w1, w3 = rec[li].w3;   // w2 = 1 - w1 - w3
-            // differences first: alpha* varies slowly, so the weights (3, -3, 1 on an even pitch) act on small numbers
-            alpha = al1 + ((R)(w1 - 1.0f) * (al1 - al2) + (R)w3 * (al3 - al2));
-        } else if (mode == 1) {
-            alpha = al1;
-        } else {
-            // first guess: polar angle of the point where the straight chord A-F meets the lens apex height
-            const R hz = -(k.phi_3 - k.twoTc + sqrt((k.phi_3 - k.twoTc) * (k.phi_3 - k.twoTc) - k.C4A)) * k.inv2A;
-            const R t = (za - hz) / (za - zf);
-            alpha = atan2(xa + t * (xf - xa), hz);
-        }
+    R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation (usable if that solve
+                                                            // ended at an interior minimum: rgp_bad below)
+    const unsigned row_bytes = (unsigned)a.n_f * (unsigned)sizeof(R);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(a.tt + (size_t)e0 * a.n_f, 0, row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((WA ? a.alpha_out : a.tt) + (size_t)e0 * a.n_f, 0, row_bytes, 0x00020000);
+    const unsigned voff = (unsigned)f_raw * (unsigned)sizeof(R);   // lanes past the last target fail the range check
+    unsigned soff = 0;                                       // li * row_bytes (< 2^32: the launcher sizes eb for it)
+
+    unsigned long long rgp_bad = ~0ull;                      // lanes whose rgp is not usable (wave-uniform mask: the test is one scalar compare)
+
+    // One solve from the start `alpha`.  Every lane holds a usable g' and the element has history (try_lite): ONE
+    // evaluation of T and g, the Newton step with the previous element's g' (g' varies by ~1e-3 from one element to the
+    // next; it only scales a step that is already below the stopping tolerance) and its second-order term — no
+    // bracket, no g'', no loop.  If any lane's step is not small, or without try_lite: the safeguarded iteration.
+    auto solve = [&](R alpha, R xa, R za, bool try_lite, R& T_out) -> R {
         alpha = fmin(fmax(alpha, a_lo), a_hi);
-        R lo = a_lo, hi = a_hi, T, g, gp = R(0);
-        // Extrapolated start and a usable g' in every lane: evaluate T and g only and take the Newton step with the
-        // g' of the previous element (g' varies by ~1e-3 from one element to the next; it only scales a step that is
-        // already below the stopping tolerance).  If any lane's step is not small, the wave runs the full iteration.
-        bool lite = false;
-        if (mode == 2 && !__builtin_amdgcn_ballot_w64(!rgp_ok)) {           // wave-uniform
-            lens_time<R, false>(k, alpha, xa, za, xf, zf, T, g, gp);
+        R T, g, gp = R(0);
+        if (try_lite && rgp_bad == 0) {                      // wave-uniform
+            lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
             const R step = -g * rgp;
-            const bool conv = !(fabs(step) > tol) || !(fabs(g * step) > tolT);
-            lite = !__builtin_amdgcn_ballot_w64(!conv);
+            const unsigned long long big = __builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT);
+            if (!big) {
+                T_out = T + R(0.5) * g * step;               // T(a*) = T(a) - g^2 / (2 g')
+                return alpha + step;
+            }
         }
+        R lo = a_lo, hi = a_hi;
         bool done = false;
-        for (int trip = 0; trip < 80 && !lite; ++trip) {    // wave-uniform trip count, ballot exit
-            lens_time<R, true>(k, alpha, xa, za, xf, zf, T, g, gp);
+        for (int trip = 0; trip < 80; ++trip) {              // wave-uniform trip count, ballot exit
+            lens_time<R, true, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
             if (g > R(0)) hi = alpha; else lo = alpha;      // T decreases left of the minimum
             rgp = rcp_r<R>(gp);
             R step = -g * rgp;
@@ -261,16 +275,62 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         }
         // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g')
         // (only where Newton converged in the interior; a minimum pinned at an interval end keeps T(alpha))
-        const bool interior = lite || (gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT)));
-        if (!lite) rgp_ok = interior;
+        const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
+        rgp_bad = __builtin_amdgcn_ballot_w64(!interior);
         const R dal = interior ? -g * rgp : R(0);
-        if (interior) T += R(0.5) * g * dal;
-        const R asol = alpha + dal;
-        // stores through a descriptor on the element's output row: 32-bit lane offsets, lanes past the last target dropped
-        store_row<R>(row, (unsigned)a.n_f, (unsigned)f_raw, T);
-        if (arow) { store_row<R>(arow, (unsigned)a.n_f, (unsigned)f_raw, asol); arow += a.n_f; }
-        row += a.n_f;
+        T_out = interior ? T + R(0.5) * g * dal : T;
+        return alpha + dal;
+    };
+    // a mode-2 element: start extrapolated from the three previous solutions (n1 the newest; differences first: alpha*
+    // varies slowly, so the weights — 3, -3, 1 on an even pitch — act on small numbers); the result replaces the oldest
+    auto step2 = [&](int idx, R n1, R n2, R& n3) {
+        const R xa = rec[idx].xa, za = rec[idx].za;
+        const float w1 = rec[idx].w1, w3 = rec[idx].w3;     // w2 = 1 - w1 - w3
+        R T;
+        const R asol = solve(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), xa, za, true, T);
+        store_at<R>(rs_t, voff, soff, T);
+        if (WA) store_at<R>(rs_a, voff, soff, asol);
+        soff += row_bytes;
+        n3 = asol;
+    };
+
+    int li = 0;
+    while (li < ne) {                                        // wave-uniform
+        const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
+        if (mode == 2) {
+            // the run of mode-2 elements from here on, unrolled by three so that the history rotates through its
+            // registers without moves
+            const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
+            for (int t = run / 3; t > 0; --t) {
+                step2(li, al1, al2, al3);                    // newest .. oldest = al3, al1, al2
+                step2(li + 1, al3, al1, al2);                //                    al2, al3, al1
+                step2(li + 2, al2, al3, al1);                //                    al1, al2, al3
+                li += 3;
+            }
+            for (int t = run % 3; t > 0; --t) {
+                step2(li, al1, al2, al3);
+                const R tn = al3; al3 = al2; al2 = al1; al1 = tn;
+                li += 1;
+            }
+            continue;
+        }
+        const R xa = rec[li].xa, za = rec[li].za;
+        R alpha;
+        if (mode == 1) {
+            alpha = al1;
+        } else {
+            // first guess: polar angle of the point where the straight chord A-F meets the lens apex height
+            const R hz = -(k.phi_3 - k.twoTc + sqrt((k.phi_3 - k.twoTc) * (k.phi_3 - k.twoTc) - k.C4A)) * k.inv2A;
+            const R t = (za - hz) / (za - zf);
+            alpha = atan2(xa + t * (xf - xa), hz);
+        }
+        R T;
+        const R asol = solve(alpha, xa, za, false, T);
+        store_at<R>(rs_t, voff, soff, T);
+        if (WA) store_at<R>(rs_a, voff, soff, asol);
+        soff += row_bytes;
         al3 = al2; al2 = al1; al1 = asol;
+        ++li;
     }
 }
 
@@ -291,8 +351,16 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     k.eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
     if (wave_solves >= 1024LL * 16 * 64) k.eb = 64;         // large tables: halves the cold starts per solve (cf. rtus_fermat.hip)
     while ((n_e + k.eb - 1) / k.eb > 65535 && k.eb < 64) ++k.eb;   // grid.y limit (eb <= 64: one lane per element)
+    if ((unsigned long long)k.eb * (unsigned long long)n_f * sizeof(R) >= 0xffffffffull) {   // row offsets inside a block are 32-bit
+        k.eb = (int)(0xffffffffull / ((unsigned long long)n_f * sizeof(R)));
+        if (k.eb < 1 || (n_e + k.eb - 1) / k.eb > 65535) return hipErrorInvalidValue;
+    }
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + k.eb - 1) / k.eb);
-    hipLaunchKernelGGL(rtus_tt_lens_kernel<R>, grid, dim3(RTUS_BLOCK), 0, s, k);
+    const bool poly = k.poly_trig != 0, wa = alpha_out != nullptr;
+    if (poly && wa) hipLaunchKernelGGL((rtus_tt_lens_kernel<R, true, true>), grid, dim3(RTUS_BLOCK), 0, s, k);
+    else if (poly) hipLaunchKernelGGL((rtus_tt_lens_kernel<R, true, false>), grid, dim3(RTUS_BLOCK), 0, s, k);
+    else if (wa) hipLaunchKernelGGL((rtus_tt_lens_kernel<R, false, true>), grid, dim3(RTUS_BLOCK), 0, s, k);
+    else hipLaunchKernelGGL((rtus_tt_lens_kernel<R, false, false>), grid, dim3(RTUS_BLOCK), 0, s, k);
     return hipGetLastError();
 }
 
