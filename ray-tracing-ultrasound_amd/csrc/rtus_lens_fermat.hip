@@ -142,10 +142,11 @@ __device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, 
 }
 
 typedef unsigned int lens_u32x2 __attribute__((ext_vector_type(2)));
-// Stores through ONE descriptor per workgroup: its base is the workgroup's first output row, its extent one row, so the
-// hardware's range check on the per-lane offset drops the lanes past the last target; the row of the current element
-// enters as the instruction's scalar offset (not range-checked; + one s_add per element instead of rebuilding a
-// descriptor from a 64-bit row pointer).
+// Stores through ONE descriptor per workgroup: its base is the workgroup's first output row, its extent the workgroup's
+// block of rows (gfx950 range-checks the scalar offset together with the per-lane one: a one-row extent drops every
+// row but the first); the row of the current element enters as the instruction's scalar offset — one s_add per element
+// instead of rebuilding a descriptor from a 64-bit row pointer.  Lanes past the last target redo the last target
+// (same inputs, same result) and store to ITS address: no exec masking, no reliance on the range check.
 template <typename R> __device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, R v);
 template <> __device__ __forceinline__ void store_at<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v)
 {
@@ -235,11 +236,12 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation (usable if that solve
                                                             // ended at an interior minimum: rgp_bad below)
     const unsigned row_bytes = (unsigned)a.n_f * (unsigned)sizeof(R);
-    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(a.tt + (size_t)e0 * a.n_f, 0, row_bytes, 0x00020000);
+    const unsigned blk_bytes = (unsigned)ne * row_bytes;     // < 2^32: the launcher sizes eb for it
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(a.tt + (size_t)e0 * a.n_f, 0, blk_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a =
-        __builtin_amdgcn_make_buffer_rsrc((WA ? a.alpha_out : a.tt) + (size_t)e0 * a.n_f, 0, row_bytes, 0x00020000);
-    const unsigned voff = (unsigned)f_raw * (unsigned)sizeof(R);   // lanes past the last target fail the range check
-    unsigned soff = 0;                                       // li * row_bytes (< 2^32: the launcher sizes eb for it)
+        __builtin_amdgcn_make_buffer_rsrc((WA ? a.alpha_out : a.tt) + (size_t)e0 * a.n_f, 0, blk_bytes, 0x00020000);
+    const unsigned voff = (unsigned)f * (unsigned)sizeof(R); // f: clamped to the last target
+    unsigned soff = 0;                                       // li * row_bytes
 
     unsigned long long rgp_bad = ~0ull;                      // lanes whose rgp is not usable (wave-uniform mask: the test is one scalar compare)
 
