@@ -143,7 +143,8 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
 // of the wave asks for a second Newton evaluation.
 template <int NL, bool ITERS, bool FAST>
 __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, const ElemRec& R, int hist, double xf,
-                                            float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f)
+                                            float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f,
+                                            __amdgpu_buffer_rsrc_t rs, unsigned soff)
 {
     const double dxs = xf - R.xe;
     const double X = fabs(dxs);
@@ -223,13 +224,13 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
     const float s2 = (0.5f * us) * (us * L.rS3);
     const double T = u * fma(L.inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
-    // store through a buffer descriptor whose base is this element's output row (wave-uniform: SGPRs) and whose
-    // extent is the row: each lane supplies a 32-bit byte offset (no 64-bit per-lane address arithmetic) and lanes
-    // beyond the last target are dropped by the range check
+    // store through the workgroup's buffer descriptor (base: its first output row, extent: its block of rows): the
+    // element's row enters as the scalar offset, each lane supplies a 32-bit byte offset (no 64-bit per-lane address
+    // arithmetic, no descriptor rebuilt per row); lanes beyond the last target have redone the last target and store
+    // to its address (gfx950 range-checks scalar + lane offset together, so a one-row extent cannot drop them)
     {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.tt + row, 0, (unsigned)a.n_f * 8u, 0x00020000);
         const u32x2 bits = {(unsigned)__double2loint(T), (unsigned)__double2hiint(T)};
-        __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, soff, 0);
         if (ITERS && live) (a.iters + row)[f] = (uint8_t)it;
     }
     // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
@@ -316,7 +317,10 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     for (int i = 0; i < NL; ++i) { L.hr[i] = L.kk[i] = L.hc[i] = 0.0; L.hrf[i] = L.kkf[i] = 0.0f; }
     float qa = 0.0f, qb = 0.0f, qc = 0.0f, qd = 0.0f;       // signed solutions of the four previous elements, qa the latest
     const size_t nf = (size_t)a.n_f;
-    size_t o = (size_t)e0 * nf;                              // output row of element e0 + li (wave-uniform)
+    size_t o = (size_t)e0 * nf;                              // output row of element e0 + li (wave-uniform; ITERS only)
+    const unsigned row_bytes = (unsigned)a.n_f * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.tt + o, 0, (unsigned)ne * row_bytes, 0x00020000);
+    unsigned so = 0;                                         // li * row_bytes (< 2^32: the launcher sizes eb for it)
     int li = 0;
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
@@ -329,17 +333,17 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         if (run4 > 0) {
             // four-history run, unrolled by four so that the history rotates through its registers without moves
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o, (unsigned)f_raw);
-                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf, (unsigned)f_raw);
-                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf, (unsigned)f_raw);
-                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf, (unsigned)f_raw);
-                o += 4 * nf;
+                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o, (unsigned)f, rs, so);
+                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf, (unsigned)f, rs, so + row_bytes);
+                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf, (unsigned)f, rs, so + 2 * row_bytes);
+                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf, (unsigned)f, rs, so + 3 * row_bytes);
+                o += 4 * nf; so += 4 * row_bytes;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o, (unsigned)f_raw);
+            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o, (unsigned)f, rs, so);
             qd = qc; qc = qb; qb = qa; qa = qn;
-            o += nf;
+            o += nf; so += row_bytes;
             ++li;
         }
     }
@@ -365,6 +369,10 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     static const char* const eb_override = getenv("RTUS_EB");   // experiments only (scripts/ab_planar.py)
     if (eb_override) eb = atoi(eb_override);
     while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
+    if ((unsigned long long)eb * (unsigned long long)n_f * 8ull >= 0xffffffffull) {   // row offsets inside a block are 32-bit
+        eb = (int)(0xffffffffull / ((unsigned long long)n_f * 8ull));
+        if (eb < 1 || (n_e + eb - 1) / eb > 65535) return hipErrorInvalidValue;
+    }
     a.eb = eb;
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb, n_batch), block(RTUS_BLOCK);
     switch (n_if + 1) {
