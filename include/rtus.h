@@ -71,6 +71,13 @@ int rtus_device_count(int *count);
 /* Frees the host-buffer twins' staging arena of `device` (all devices: -1).  Optional: a process that exits without
  * calling it leaks nothing the driver does not reclaim. */
 int rtus_release(int device);
+/* Diagnostic (not in the reference): checks, on `device`, two facts the forward trace relies on — (a) its correctly
+ * rounded division / square root sequences return the bits of a / b and sqrt(a) on n_math pseudo-random operand pairs
+ * (exponents within +-500, every special value), (b) the depth-first bounding-box records of an n_rays-point lens
+ * polyline form a tree (forward skip links that land where each box ends, leaves covering the polyline in order).
+ * counts[0] = division mismatches, [1] = square-root mismatches, [2] = structure violations, [3] = n_math.  All zero
+ * on a healthy build. */
+int rtus_selftest(const rtus_lens *lens, int n_rays, long long n_math, unsigned long long *counts, int device);
 
 /* ------------------------------------------------------------------------------------------
  * Forward trace — replaces shoot_rays (main_rt.py:337-405, 432-441) and its helpers

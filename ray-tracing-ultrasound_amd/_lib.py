@@ -67,6 +67,8 @@ def lib():
     L.rtus_device_count.argtypes = [C.POINTER(C.c_int)]
     L.rtus_release.argtypes = [ip]
     L.rtus_release.restype = ip
+    L.rtus_selftest.argtypes = [C.POINTER(Lens), ip, C.c_longlong, C.POINTER(C.c_ulonglong), ip]
+    L.rtus_selftest.restype = ip
     L.rtus_shoot_workspace_bytes.argtypes = [ip]
     L.rtus_shoot_workspace_bytes.restype = C.c_size_t
     LP = C.POINTER(Lens)
@@ -112,7 +114,7 @@ def check(status, what):
         raise RtusError(status, what)
 
 
-EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count", "rtus_release",
+EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_count", "rtus_release", "rtus_selftest",
            "rtus_shoot_workspace_bytes", "rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match",
            "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_tt_layers_batch_dev",
            "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",

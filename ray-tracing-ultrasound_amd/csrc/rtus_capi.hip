@@ -9,6 +9,7 @@
 
 // launchers (rtus_shoot.hip / rtus_match.hip / rtus_fermat.hip)
 size_t rtus_ws_bytes(int n);
+hipError_t rtus_selftest_run(const rtus_lens& lens, int n, long long n_math, unsigned long long counts[4], hipStream_t s);
 hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
@@ -238,6 +239,14 @@ int rtus_device_count(int* count)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return RTUS_ERR_NO_DEVICE; }
     *count = n;
+    return RTUS_OK;
+}
+
+int rtus_selftest(const rtus_lens* lens, int n_rays, long long n_math, unsigned long long* counts, int device)
+{
+    if (!lens || !counts || n_rays < 8 || n_math < 0 || n_math > (1ll << 36)) return RTUS_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(rtus_selftest_run(*lens, n_rays, n_math, counts, (hipStream_t)0));
     return RTUS_OK;
 }
 

@@ -22,6 +22,7 @@
 // index is found — it only avoids evaluating points whose sign is already certain — so the result
 // is the reference's "first sign change in index order", np.sign(0) = 0 semantics included.
 #include "rtus_device.h"
+#include <vector>
 
 #define RTUS_CURVE_TPB 512      // curve kernel: one workgroup = one 512-point node2
 
@@ -850,6 +851,91 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
     if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL(rtus_shoot_kernel<true>, grid, dim3(RTUS_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rtus_shoot_kernel<false>, grid, dim3(RTUS_BLOCK), 0, s, a);
     return hipGetLastError();
+}
+
+// ---- self-test (rtus_selftest): the claims the forward trace leans on, checked on the device it runs on -------------
+// (1) rtus_div / rtus_sqrt return the bits of the correctly rounded a / b and sqrt(a) — over pseudo-random operands with
+//     exponents in +-500 and every special value (+-0, +-inf, NaN, +-1, the smallest normal; quotients that come out
+//     denormal are outside rtus_div's contract and not counted); (2) the depth-first records rtus_tree_kernel
+//     builds are a tree: skip links move forward and land on the record that starts where the box ends, leaves cover the
+//     polyline in order.
+__device__ __forceinline__ unsigned long long selftest_mix(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double selftest_operand(unsigned long long r)
+{
+    const double specials[8] = {0.0, -0.0, INFINITY, -INFINITY, NAN, 1.0, -1.0, 2.2250738585072014e-308};
+    if ((r & 63) == 0) return specials[(r >> 6) & 7];
+    const unsigned long long mant = r >> 12, sign = (r >> 11) & 1;
+    const int e = (int)((r >> 1) % 1001) - 500;                      // 2^-500 .. 2^500
+    return rtus_from_bits((sign << 63) | ((unsigned long long)(e + 1023) << 52) | mant);
+}
+__global__ void rtus_selftest_math_kernel(unsigned long long seed, long long n, unsigned long long* __restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = selftest_operand(selftest_mix(seed + 2 * (unsigned long long)i));
+    const double b = selftest_operand(selftest_mix(seed + 2 * (unsigned long long)i + 1));
+    const double q1 = rtus_div(a, b), q2 = a / b;
+    const double s1 = rtus_sqrt(a), s2 = sqrt(a);
+    const bool q_denormal = q2 != 0.0 && fabs(q2) < 2.2250738585072014e-308;     // outside rtus_div's contract (no pre-scaling)
+    if (rtus_bits(q1) != rtus_bits(q2) && !(q1 != q1 && q2 != q2) && !q_denormal) atomicAdd(bad, 1ull);
+    if (rtus_bits(s1) != rtus_bits(s2) && !(s1 != s1 && s2 != s2)) atomicAdd(bad + 1, 1ull);
+}
+
+hipError_t rtus_selftest_run(const rtus_lens& lens, int n, long long n_math, unsigned long long counts[4], hipStream_t s)
+{
+    counts[0] = counts[1] = counts[2] = 0; counts[3] = (unsigned long long)n_math;
+    unsigned long long* d_bad = nullptr;
+    hipError_t e = hipMalloc(&d_bad, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    (void)hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(rtus_selftest_math_kernel, dim3((unsigned)((n_math + 255) / 256)), dim3(256), 0, s, 0x1234567ull, n_math, d_bad);
+    // the tree of an n-point polyline on the reference's launch-angle interval
+    ShootArgs a;
+    a.k = make_lens_k(lens);
+    char* w = nullptr;
+    double* d_alpha = nullptr;
+    if ((e = hipMalloc(&w, rtus_ws_bytes(n))) != hipSuccess || (e = hipMalloc(&d_alpha, sizeof(double) * n)) != hipSuccess) {
+        (void)hipFree(d_bad); (void)hipFree(w); return e;
+    }
+    std::vector<double> alpha(n);
+    const double amax = 50.62033040986099 * (3.14159265358979323846 / 180.0);
+    for (int i = 0; i < n; ++i) alpha[i] = n > 1 ? -amax + 2.0 * amax * i / (n - 1) : 0.0;
+    (void)hipMemcpyAsync(d_alpha, alpha.data(), sizeof(double) * n, hipMemcpyHostToDevice, s);
+    shoot_args_workspace(a, w, n);
+    hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, d_alpha, n, (double2*)a.curve, (double*)a.phi_s,
+                       (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1, (double4*)a.node2);
+    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
+                       a.n3, (TreeNode*)a.tree);
+    std::vector<TreeNode> t(a.n_tree + 1);
+    unsigned long long bad[2] = {0, 0};
+    (void)hipMemcpyAsync(t.data(), a.tree, sizeof(TreeNode) * t.size(), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s);
+    e = hipStreamSynchronize(s);
+    (void)hipFree(d_bad); (void)hipFree(w); (void)hipFree(d_alpha);
+    if (e != hipSuccess) return e;
+    counts[0] = bad[0]; counts[1] = bad[1];
+    unsigned long long viol = 0;
+    const unsigned end = (unsigned)a.n_tree * (unsigned)sizeof(TreeNode);
+    int next_leaf = 0;
+    for (int i = 0; i < a.n_tree; ++i) {
+        const TreeNode& r = t[i];
+        const unsigned off = (unsigned)i * (unsigned)sizeof(TreeNode);
+        const bool leaf = r.leafm != 0;
+        if (!(r.skip_off > off && r.skip_off <= end && r.skip_off % sizeof(TreeNode) == 0)) { ++viol; continue; }
+        if (leaf != (r.j1 - r.j0 == 8) || (r.leafm != 0 && r.leafm != ~0ull) || !(r.xh >= 0.0 && r.zh >= 0.0)) ++viol;
+        if (leaf) { if (r.j0 != next_leaf || r.skip_off != off + sizeof(TreeNode)) ++viol; next_leaf += 8; }
+        else if (t[i + 1].j0 != r.j0) ++viol;                       // an inner box is followed by its first child
+        const unsigned nx = r.skip_off / (unsigned)sizeof(TreeNode);
+        if (nx < (unsigned)a.n_tree && t[nx].j0 != r.j1) ++viol;   // past the subtree: the box that starts where this one ends
+        if (nx == (unsigned)a.n_tree && r.j1 < n) ++viol;          // ... or the end of the polyline
+    }
+    if (next_leaf != ((n + 7) & ~7)) ++viol;
+    counts[2] = viol;
+    return hipSuccess;
 }
 
 #ifdef RTUS_EXP_COUNT   // experiment builds only (scripts/exp_count.py)
