@@ -328,7 +328,7 @@ def main(argv=None):
             xe, ze, xf, zf = t32(W["xe"]), t32(W["ze"]), t32(W["xf"]), t32(W["zf"])
             lens = rtus.Params().lens()
             fn = rtus.lib().rtus_tt_lens_f32_dev
-            kernel = "rtus_tt_lens_kernel<float>"
+            kernel = "rtus_tt_lens_kernel<float, true, false>"
 
             def launch(b):
                 st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, xf.data_ptr(),
