@@ -120,3 +120,46 @@ def test_reference_scale_up_batch_consistency(rtus):
         assert np.array_equal(np.isnan(o[6]), np.isnan(b1["land_x"][0, t]))
         m = ~np.isnan(o[6])
         assert np.max(np.abs(o[6] - b1["land_x"][0, t])[m]) < 1e-11
+
+
+def test_row_offsets_of_a_very_wide_table_stay_in_32_bits(rtus):
+    """The table kernels store through one buffer descriptor per workgroup with the row as a 32-bit scalar offset; the
+    launcher shrinks the element block when eb x n_f x word would not fit.  n_f = 2^27 targets: 64 rows of fp64 would span
+    64 GiB, the launcher has to fall to 3 rows per block (planar) / 7 rows (fp32 lens).  Every row of the wide launch
+    must equal the same targets solved in a narrow launch."""
+    import ctypes as C
+    import torch
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    n_f, n_e = 1 << 27, 5
+    xe = (np.arange(n_e) - 2.0) * 0.3e-3
+    xf = torch.linspace(-0.02, 0.02, n_f, dtype=torch.float64, device="cuda")
+    zf = torch.full((n_f,), 0.04, dtype=torch.float64, device="cuda")
+    z_if, c = [0.010, 0.025], [2330.0, 1483.0, 5900.0]
+    wide = dev_api.tt_layers_dev(z_if, c, _t(xe), _t(np.zeros(n_e)), xf, zf)
+    torch.cuda.synchronize()
+    assert wide.shape == (n_e, n_f) and bool(torch.isfinite(wide).all())
+    sel = torch.cat([torch.arange(0, 4096, device="cuda"), torch.arange(n_f - 4096, n_f, device="cuda"),
+                     torch.randint(0, n_f, (8192,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))])
+    narrow = dev_api.tt_layers_dev(z_if, c, _t(xe), _t(np.zeros(n_e)), xf[sel].contiguous(), zf[sel].contiguous())
+    assert float((wide[:, sel] - narrow).abs().max()) < 1e-15
+    del wide, narrow
+    # fp32 lens kernel, same width
+    L = rtus.lib()
+    lens = rtus.Params().lens()
+    n_e = 9
+    xe32 = _t((np.arange(n_e) - 4.0) * 0.3e-3, np.float32)
+    ze32 = _t(np.full(n_e, D_PLANE), np.float32)
+    xf32 = torch.linspace(-0.004, 0.004, n_f, dtype=torch.float32, device="cuda")
+    zf32 = torch.full((n_f,), 0.05, dtype=torch.float32, device="cuda")
+    out = torch.full((n_e, n_f), -1.0, dtype=torch.float32, device="cuda")
+    st = L.rtus_tt_lens_f32_dev(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe32.data_ptr(), ze32.data_ptr(), n_e, xf32.data_ptr(),
+                                zf32.data_ptr(), n_f, out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert bool((out > 0).all())                                           # every row written
+    xs, zs = xf32[sel].contiguous(), zf32[sel].contiguous()
+    small = torch.empty((n_e, sel.numel()), dtype=torch.float32, device="cuda")
+    st = L.rtus_tt_lens_f32_dev(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe32.data_ptr(), ze32.data_ptr(), n_e, xs.data_ptr(),
+                                zs.data_ptr(), sel.numel(), small.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    assert float((out[:, sel] - small).abs().max()) < 2e-10                # the stated fp32 tolerance
