@@ -114,7 +114,7 @@ def shoot_batch(x_a, z_a, z_f, alpha, geoms=None, *, params: Params = None, want
 
     geoms: [n_geom, 2] of (r_outer, pipe_offset); default = the one geometry in ``params``.
     want:  any of "out8" [G,T,8,N], "tof4" [G,T,4,N], "tof" [G,T,N], "land_x" [G,T,N], "status".
-    fast:  vector-form arithmetic (no trigonometry; measured 1.5-1.6x faster); the default reproduces the reference's
+    fast:  vector-form arithmetic (no trigonometry; measured 1.6-1.7x faster); the default reproduces the reference's
            angle-form arithmetic operation for operation.
     """
     p = _resolve(params)
