@@ -76,6 +76,15 @@ __device__ __forceinline__ float tfm_tau(double t, double fs, double half_t0s)
     return (t == t) ? v : -1.0e8f;
 }
 
+// Two neighbouring samples i, i + 1 of one A-scan (wave-uniform base) in one 8-byte load; an index outside the record
+// (negative, huge, the no-path sentinel) is dropped by the descriptor's range check and reads as zeros.
+#define RTUS_TFM_GROUP 16
+__device__ __forceinline__ tfm_u32x2 tfm_load2(const float* rec, int n_t, int i)
+{
+    const __amdgpu_buffer_rsrc_t q = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)n_t * 4u, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b64(q, (unsigned)i * 4u, 0, 0);
+}
+
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
 {
     __shared__ float tau_rx[RTUS_TFM_RX_TILE][RTUS_BLOCK];           // 32 KB: 5 workgroups per CU
@@ -89,20 +98,36 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
         __syncthreads();                                              // the previous tile is no longer read
         for (int r = 0; r < nr; ++r) tau_rx[r][threadIdx.x] = tfm_tau(a.tt_rx[(size_t)(r0 + r) * nf + f], a.fs, a.half_t0s);
         __syncthreads();
+        // Sixteen receive elements per trip: 16 independent gathers in flight per lane, ALL issued before the first is
+        // consumed (two explicit phases: left to itself the scheduler pairs each load with its use).  An image of
+        // 256 x 256 focal points is 1024 waves — one per SIMD — so nothing but the wave's own loads hides the ~1 us a
+        // gather takes: 4 in flight 441 us, 8: 282 us, 16: 214 us, 32 (two transmit elements at once): 218 us — from 16 on
+        // the vector-memory address path binds (64 scattered 8-byte requests per wave-instruction, ~27 cycles each per CU).
         for (int tx = 0; tx < a.n_tx; ++tx) {
             const float tt = tfm_tau(a.tt_tx[(size_t)tx * nf + f], a.fs, a.half_t0s);
             const float* rec = a.fmc + ((size_t)tx * a.n_rx + r0) * (size_t)a.n_t;   // wave-uniform
-#pragma unroll 4
-            for (int r = 0; r < nr; ++r) {
+            int r = 0;
+            for (; r + RTUS_TFM_GROUP <= nr; r += RTUS_TFM_GROUP) {
+                tfm_u32x2 v[RTUS_TFM_GROUP];
+                float w[RTUS_TFM_GROUP];
+#pragma unroll
+                for (int k = 0; k < RTUS_TFM_GROUP; ++k) {
+                    const float s = tt + tau_rx[r + k][threadIdx.x];
+                    const float fl = floorf(s);
+                    w[k] = s - fl;
+                    v[k] = tfm_load2(rec + (size_t)(r + k) * a.n_t, a.n_t, (int)fl);
+                }
+#pragma unroll
+                for (int k = 0; k < RTUS_TFM_GROUP; ++k) {
+                    const float v0 = __uint_as_float(v[k].x), v1 = __uint_as_float(v[k].y);
+                    acc += fmaf(w[k], v1 - v0, v0);
+                }
+            }
+            for (; r < nr; ++r) {                                     // receive elements past the last full group
                 const float s = tt + tau_rx[r][threadIdx.x];
                 const float fl = floorf(s);
-                const float w = s - fl;
-                const int i = (int)fl;                                // negative / huge: dropped by the range check
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(rec + (size_t)r * a.n_t), 0,
-                                                                                    (unsigned)a.n_t * 4u, 0x00020000);
-                const tfm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)i * 4u, 0, 0);
-                const float v0 = __uint_as_float(v.x), v1 = __uint_as_float(v.y);
-                acc += fmaf(w, v1 - v0, v0);
+                const tfm_u32x2 v = tfm_load2(rec + (size_t)r * a.n_t, a.n_t, (int)fl);
+                acc += fmaf(s - fl, __uint_as_float(v.y) - __uint_as_float(v.x), __uint_as_float(v.x));
             }
         }
     }
