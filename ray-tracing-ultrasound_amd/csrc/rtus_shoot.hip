@@ -1,7 +1,7 @@
 // rtus_shoot.hip — forward 4-segment ray trace (reference shoot_rays, main_rt.py:337-405) for
 // gfx950: one ray per lane, 64-lane waves walking the lens polyline in lock-step.
 //
-// Layout in HBM (workspace, built once per call by rtus_curve_kernel; shared by every tx / geometry)
+// Layout in HBM (workspace, built once per call by rtus_curve_kernel + rtus_tree_kernel; shared by every tx / geometry)
 //   curve   double2[n]        (x_p, z_p) of the alpha grid
 //   phi_s   double[n]         atan2(dz, dx) of the lens tangent at alpha[j]
 //   tan_u   double2[n]        the same tangent as a unit vector (fast-math mode)
