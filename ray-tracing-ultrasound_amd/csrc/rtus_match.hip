@@ -17,6 +17,7 @@ struct MatchArgs {
     double atol, rtol;
     int n, n_rx, n_batch;
     int row0;                           // first batch row of this launch (grid.y is limited to 65535 rows)
+    int chunks;                         // 256-ray chunks per workgroup (the aperture is staged once per workgroup)
 };
 
 // Workgroup = 256 rays of one batch row.  LDS: x_rx[n_rx] then tol[n_rx] (dynamic).
@@ -45,30 +46,35 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
     amax = fmax(fmax(s_amax[0], s_amax[1]), fmax(s_amax[2], s_amax[3]));
     const double win = a.atol + a.rtol * amax;
 
-    const int r = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const int row = a.row0 + blockIdx.y;
-    if (r >= a.n) return;
-    const double x = a.land_x[(size_t)row * a.n + r];
-    bool any = false;
-    if (isfinite(x)) {                             // NaN / inf never match a finite element
-        int e0 = 0, e1 = a.n_rx;
-        if (sorted) {                              // lower_bound(x - win)
-            const double lo = x - win;
-            int l = 0, h = a.n_rx;
-            while (l < h) { const int mid = (l + h) >> 1; if (sx[mid] < lo) l = mid + 1; else h = mid; }
-            e0 = l;
-        }
-        for (int e = e0; e < e1; ++e) {
-            const double xe = sx[e];
-            if (sorted && xe > x + win) break;
-            if (fabs(x - xe) <= stol[e]) {
-                any = true;
-                if (a.first_ray) atomicMin(&a.first_ray[(size_t)row * a.n_rx + e], r);
-                else break;
+    // `chunks` consecutive 256-ray chunks of the row per workgroup: staging the aperture (a dependent chain of loads, two
+    // reductions and a barrier: ~3 us) is paid once per workgroup, and at 256 rays per workgroup it WAS the kernel on
+    // large batches (8.4 M rays: 32,768 workgroups, 16 rounds of that latency)
+    for (int c = 0; c < a.chunks; ++c) {
+        const int r = (blockIdx.x * a.chunks + c) * RTUS_BLOCK + threadIdx.x;
+        if (r >= a.n) return;                      // (no barrier below: a thread may leave alone)
+        const double x = a.land_x[(size_t)row * a.n + r];
+        bool any = false;
+        if (isfinite(x)) {                         // NaN / inf never match a finite element
+            int e0 = 0, e1 = a.n_rx;
+            if (sorted) {                          // lower_bound(x - win)
+                const double lo = x - win;
+                int l = 0, h = a.n_rx;
+                while (l < h) { const int mid = (l + h) >> 1; if (sx[mid] < lo) l = mid + 1; else h = mid; }
+                e0 = l;
+            }
+            for (int e = e0; e < e1; ++e) {
+                const double xe = sx[e];
+                if (sorted && xe > x + win) break;
+                if (fabs(x - xe) <= stol[e]) {
+                    any = true;
+                    if (a.first_ray) atomicMin(&a.first_ray[(size_t)row * a.n_rx + e], r);
+                    else break;
+                }
             }
         }
+        if (a.ray_hit) a.ray_hit[(size_t)row * a.n + r] = any ? 1 : 0;
     }
-    if (a.ray_hit) a.ray_hit[(size_t)row * a.n + r] = any ? 1 : 0;
 }
 
 // first_ray sentinel -> -1, hit flag, tof of the first hitting ray (0.0 when none: main_rt.py:493).
@@ -100,9 +106,14 @@ hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batc
         hipError_t e = hipMemsetAsync(first_ray, 0x7f, (size_t)n_batch * n_rx * sizeof(int32_t), s);
         if (e != hipSuccess) return e;
     }
+    // chunks per workgroup: as many as leave >= ~2048 workgroups (8 per CU) in the launch, at most 16
+    const long long blocks = (long long)((n + RTUS_BLOCK - 1) / RTUS_BLOCK) * n_batch;
+    long long chunks = blocks / 2048;
+    a.chunks = (int)(chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks));
+    const int per_wg = RTUS_BLOCK * a.chunks;
     for (int row0 = 0; row0 < n_batch; row0 += 65535) {
         a.row0 = row0;
-        hipLaunchKernelGGL(rtus_match_kernel, dim3((n + RTUS_BLOCK - 1) / RTUS_BLOCK, min(65535, n_batch - row0)),
+        hipLaunchKernelGGL(rtus_match_kernel, dim3((n + per_wg - 1) / per_wg, min(65535, n_batch - row0)),
                            dim3(RTUS_BLOCK), lds, s, a);
     }
     if (first_ray) {
