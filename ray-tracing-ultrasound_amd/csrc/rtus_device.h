@@ -15,7 +15,9 @@
 // Restates the scalar prologue of h_from_alpha / dh_from_alpha (main_rt.py:181-201).
 struct LensK {
     double c1, c2, d;
-    double inv_c1, inv_c2;   // 1/c1, 1/c2 (host-rounded; used by the vector-form mode only)
+    double inv_c1, inv_c2;   // 1/c1, 1/c2, host-rounded: the vector-form mode multiplies by them, the compat mode divides through
+                             // them (rtus_div_by: correctly rounded)
+    double inv_twoA;         // 1/(2A), likewise
     double eta12, eta21;     // c1/c2, c2/c1: the refraction ratios of main_rt.py:398 / :345, divided once on the host
     double A;        // c1^2/c2^2 - 1                    main_rt.py:183
     double C4A;      // 4*A*C, C = c1^2 T^2 - d^2        main_rt.py:185, 172
@@ -38,6 +40,7 @@ static inline LensK make_lens_k(const rtus_lens& L)
     double C = c1sq * (T * T) - L.d * L.d;
     k.C4A = 4.0 * k.A * C;
     k.twoA = 2.0 * k.A;
+    k.inv_twoA = 1.0 / k.twoA;
     k.phi_1 = -1.0 / (2.0 * k.A);
     k.phi_2 = (-2.0 * T * c1sq) / L.c2;
     k.phi_3 = 2.0 * L.d;
@@ -55,7 +58,7 @@ __device__ __forceinline__ void lens_eval_sc(const LensK& k, double s, double c,
 {
     double B = k.phi_3 * c - k.twoTc;              // 2 d cos(a) - 2 T c1^2/c2
     double sq = rtus_sqrt(B * B - k.C4A);
-    double h = rtus_div(-B - sq, k.twoA);
+    double h = rtus_div_by(-B - sq, k.twoA, k.inv_twoA);
     double dB = -k.phi_3 * s;
     double dS = rtus_div(1.0, 2.0 * sq) * (2.0 * B * dB);
     double dh = k.phi_1 * (dB + dS);

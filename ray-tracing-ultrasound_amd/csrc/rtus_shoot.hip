@@ -333,7 +333,7 @@ template <bool FAST> __device__ __forceinline__ double m_sqrt(double x)
 template <bool FAST> __device__ __forceinline__ double seg_time(double x1, double z1, double x2, double z2, double c,
                                                                  double inv_c)
 {
-    if (!FAST) return rtus_div(dist2d(x1, z1, x2, z2), c);
+    if (!FAST) return rtus_div_by(dist2d(x1, z1, x2, z2), c, inv_c);
     const double dx = x1 - x2, dz = z1 - z2;
     return m_sqrt<true>(dx * dx + dz * dz) * inv_c;
 }
@@ -854,7 +854,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
 }
 
 // ---- self-test (rtus_selftest): the claims the forward trace leans on, checked on the device it runs on -------------
-// (1) rtus_div / rtus_sqrt return the bits of the correctly rounded a / b and sqrt(a) — over pseudo-random operands with
+// (1) rtus_div / rtus_div_by / rtus_sqrt return the bits of the correctly rounded a / b and sqrt(a) — over pseudo-random operands with
 //     exponents in +-500 and every special value (+-0, +-inf, NaN, +-1, the smallest normal; quotients that come out
 //     denormal are outside rtus_div's contract and not counted); (2) the depth-first records rtus_tree_kernel
 //     builds are a tree: skip links move forward and land on the record that starts where the box ends, leaves cover the
@@ -872,7 +872,8 @@ __device__ __forceinline__ double selftest_operand(unsigned long long r)
     const int e = (int)((r >> 1) % 1001) - 500;                      // 2^-500 .. 2^500
     return rtus_from_bits((sign << 63) | ((unsigned long long)(e + 1023) << 52) | mant);
 }
-__global__ void rtus_selftest_math_kernel(unsigned long long seed, long long n, unsigned long long* __restrict__ bad)
+struct SelftestDivisors { double c[8], rc[8]; };
+__global__ void rtus_selftest_math_kernel(unsigned long long seed, long long n, SelftestDivisors d, unsigned long long* __restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -883,6 +884,11 @@ __global__ void rtus_selftest_math_kernel(unsigned long long seed, long long n, 
     const bool q_denormal = q2 != 0.0 && fabs(q2) < 2.2250738585072014e-308;     // outside rtus_div's contract (no pre-scaling)
     if (rtus_bits(q1) != rtus_bits(q2) && !(q1 != q1 && q2 != q2) && !q_denormal) atomicAdd(bad, 1ull);
     if (rtus_bits(s1) != rtus_bits(s2) && !(s1 != s1 && s2 != s2)) atomicAdd(bad + 1, 1ull);
+    // division by a wave-uniform divisor through its host-rounded reciprocal (sound speeds, the lens constant 2A, ...)
+    const int j = blockIdx.x & 7;
+    const double u1 = rtus_div_by(a, d.c[j], d.rc[j]), u2 = a / d.c[j];
+    const bool u_denormal = u2 != 0.0 && fabs(u2) < 2.2250738585072014e-308;
+    if (rtus_bits(u1) != rtus_bits(u2) && !(u1 != u1 && u2 != u2) && !u_denormal) atomicAdd(bad, 1ull);
 }
 
 hipError_t rtus_selftest_run(const rtus_lens& lens, int n, long long n_math, unsigned long long counts[4], hipStream_t s)
@@ -892,7 +898,11 @@ hipError_t rtus_selftest_run(const rtus_lens& lens, int n, long long n_math, uns
     hipError_t e = hipMalloc(&d_bad, 2 * sizeof(unsigned long long));
     if (e != hipSuccess) return e;
     (void)hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(rtus_selftest_math_kernel, dim3((unsigned)((n_math + 255) / 256)), dim3(256), 0, s, 0x1234567ull, n_math, d_bad);
+    SelftestDivisors dv;
+    const LensK kk = make_lens_k(lens);
+    const double divisors[8] = {lens.c1, lens.c2, kk.twoA, 1483.0, 5900.0, 2330.0, 0.7853981633974483, 6399.999999999999};
+    for (int i = 0; i < 8; ++i) { dv.c[i] = divisors[i]; dv.rc[i] = 1.0 / divisors[i]; }
+    hipLaunchKernelGGL(rtus_selftest_math_kernel, dim3((unsigned)((n_math + 255) / 256)), dim3(256), 0, s, 0x1234567ull, n_math, dv, d_bad);
     // the tree of an n-point polyline on the reference's launch-angle interval
     ShootArgs a;
     a.k = make_lens_k(lens);
