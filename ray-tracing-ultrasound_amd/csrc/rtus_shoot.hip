@@ -353,7 +353,7 @@ struct RayOut { double xq, zq, xi, zi, x_in; };
 
 // Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan /
 // atan2 / atan / asin through the kernels of rtus_trig.h, correctly rounded division and square root (rtus_div,
-// rtus_sqrt) and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho (no angle formed): 1,212 instead
+// rtus_sqrt) and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho (no angle formed): 1,200 instead
 // of 2,066 executed VALU instructions per wave.  ONE place keeps the library's routines: the first refraction of a wave
 // that holds a near-vertical refracted line (|a_pq| > 300: ~1 % of the waves).  The
 // reference intersects that line with the pipe through the quadratic formula in slope-intercept form
