@@ -409,7 +409,9 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     const double qC = off * off + b_pq * b_pq - r_outer * r_outer;
     const double sq = m_sqrt<FAST>(qB * qB - 4.0 * qA * qC);
     const double den = 2.0 * qA;
-    const double xq1 = m_div<FAST>(-qB + sq, den), xq2 = m_div<FAST>(-qB - sq, den);
+    double xq1, xq2;
+    if (FAST) { const double rd = rcp_fast(den); xq1 = (-qB + sq) * rd; xq2 = (-qB - sq) * rd; }
+    else rtus_div2(-qB + sq, -qB - sq, den, xq1, xq2);
     const double zq1 = a_pq * xq1 + b_pq, zq2 = a_pq * xq2 + b_pq;
     const bool upper = zq1 > zq2;
     const double xq = upper ? xq1 : xq2, zq = upper ? zq1 : zq2;
@@ -583,7 +585,9 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         // :396-397 alpha_i = atan2(x_i, z_i) is only ever used through its sine and cosine: x_i / rho, z_i / rho
         const double rho = rtus_sqrt(xi * xi + zi * zi);
         double lx, lz, ldz, ldx;
-        lens_eval_sc(k, rtus_div(xi, rho), rtus_div(zi, rho), lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
+        double si, ci;
+        rtus_div2(xi, zi, rho, si, ci);
+        lens_eval_sc(k, si, ci, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
         const double phi_last = refract_angle(phi_l, rtus_atan2(ldz, ldx), k.eta12);   // :398
         a3 = rtus_tan(phi_last);                                       // :401
     } else {
