@@ -799,11 +799,11 @@ def consumer_measurements(dev_api, t64, torch, dev):
     ms = _event_ms(torch, lambda: dev_api.focal_delays_dev(tt3, out=out), 10)
     n = tt3.numel()
     res["focal_delays_cfg3"] = {"ms_per_launch": round(ms, 4), "entries": n,
-                                "roofline": {"bound": "hbm", "kernel": "rtus_focal_delays_kernel", "algorithmic_bytes_per_launch": 16 * n,
+                                "roofline": {"bound": "hbm", "kernel": "rtus_focal_delays_once_kernel<32>", "algorithmic_bytes_per_launch": 16 * n,
                                              "achieved": round(16 * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": round(16 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                             "note": "8 B read + 8 B written per entry; the second read of the table (column "
-                                                     "maximum first, then subtract) is 8 B more when the strip has left the caches"}}
+                                             "note": "8 B read + 8 B written per entry: the column stays in registers between the maximum and "
+                                                     "the subtraction (apertures up to 512 elements)"}}
     del tt3, out
     n_el, n_t, fs = 64, 2048, 50e6
     xe = (np.arange(n_el) - (n_el - 1) / 2.0) * 0.6e-3

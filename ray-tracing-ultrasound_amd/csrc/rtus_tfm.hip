@@ -4,8 +4,8 @@
 // point-scatterer data.
 //
 // Unlike every other kernel of this library these two are bound by memory, not by VALU issue:
-//   * rtus_focal_delays_kernel streams the table: 8 B read for the column maximum, 8 B re-read (L2 / Infinity Cache
-//     when a 256-column strip of the table fits) and 8 B written per entry -> HBM roofline, 16-24 B per entry;
+//   * the focal-law kernels stream the table: 8 B read and 8 B written per entry (apertures up to 512 elements: the
+//     column lives in registers between the maximum and the subtraction; larger ones re-read it: 24 B) -> HBM roofline;
 //   * rtus_tfm_kernel gathers two neighbouring fp32 samples per (tx, rx, focal point) from the A-scan of that pair:
 //     8 B of L2 traffic per pair and focal point.  The FMC block (n_tx n_rx n_t 4 B: 34 MB at 64 x 64 x 2048) is read
 //     from HBM about once per launch and then lives in L2 / Infinity Cache, so the bound is the L2 gather rate
@@ -37,10 +37,54 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_focal_delays_kernel(const dou
     }
 }
 
+// The same for apertures of up to 8 x RTUS_FD_ROWS elements, reading the table ONCE: a workgroup = 32 focal points x 8 row
+// groups; a thread keeps its <= RTUS_FD_ROWS entries of one column in registers, the eight partial maxima of a column meet
+// in LDS, and the thread subtracts and writes from its registers (in place is safe: a thread only writes what it has
+// read).  16 B of HBM traffic per entry instead of 24 (measured on the 537 MB configs[2] table: the strip a workgroup of
+// the two-pass kernel comes back to has long left the caches).  Lanes 0-31 of a wave are 32 neighbouring columns of one
+// row, lanes 32-63 the same columns 1/8 of the aperture further down: two 256-byte segments per load.
+#define RTUS_FD_ROWS 64
+template <int ROWS>
+__global__ __launch_bounds__(RTUS_BLOCK) void rtus_focal_delays_once_kernel(const double* tt, int n_e, int n_f, double* delays)
+{
+    __shared__ double part[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;             // column inside the tile, row group
+    const int f_raw = blockIdx.x * 32 + c;
+    const bool live = f_raw < n_f;
+    const int f = live ? f_raw : n_f - 1;
+    const int per = (n_e + 7) / 8;                                     // rows per group (<= ROWS)
+    const int e0 = g * per;
+    const size_t nf = (size_t)n_f;
+    double v[ROWS];
+    double m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int e = e0 + k;
+        v[k] = (k < per && e < n_e) ? tt[(size_t)e * nf + f] : NAN;   // NaN: ignored by fmax, never stored
+        m = fmax(m, v[k]);
+    }
+    part[g][c] = m;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmax(m, part[j][c]);
+    m = (m == -INFINITY) ? NAN : m;                                    // no element reaches this focal point
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int e = e0 + k;
+        if (k < per && e < n_e) delays[(size_t)e * nf + f] = m - v[k];
+    }
+}
+
 hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* delays, hipStream_t s)
 {
-    hipLaunchKernelGGL(rtus_focal_delays_kernel, dim3((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK), dim3(RTUS_BLOCK), 0, s, tt, n_e, n_f,
-                       delays);
+    const int per = (n_e + 7) / 8;
+    const dim3 grid1((n_f + 31) / 32), block(RTUS_BLOCK);
+    if (per <= 8) hipLaunchKernelGGL(rtus_focal_delays_once_kernel<8>, grid1, block, 0, s, tt, n_e, n_f, delays);
+    else if (per <= 16) hipLaunchKernelGGL(rtus_focal_delays_once_kernel<16>, grid1, block, 0, s, tt, n_e, n_f, delays);
+    else if (per <= 32) hipLaunchKernelGGL(rtus_focal_delays_once_kernel<32>, grid1, block, 0, s, tt, n_e, n_f, delays);
+    else if (per <= RTUS_FD_ROWS) hipLaunchKernelGGL(rtus_focal_delays_once_kernel<RTUS_FD_ROWS>, grid1, block, 0, s, tt, n_e, n_f, delays);
+    else hipLaunchKernelGGL(rtus_focal_delays_kernel, dim3((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK), block, 0, s, tt, n_e, n_f, delays);
     return hipGetLastError();
 }
 
