@@ -98,7 +98,7 @@ hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* 
 // A-scan of a pair is addressed through a buffer descriptor whose base is wave-uniform (SGPRs) and whose extent is
 // the record: the hardware's range check returns 0 for a sample index outside [0, n_t) — no compare / select in the
 // inner loop — and the two neighbouring samples come in one 8-byte load.
-#define RTUS_TFM_RX_TILE 32
+#define RTUS_TFM_RX_TILE 64
 typedef unsigned int tfm_u32x2 __attribute__((ext_vector_type(2)));
 
 struct TfmArgs {
@@ -131,7 +131,8 @@ __device__ __forceinline__ tfm_u32x2 tfm_load2(const float* rec, int n_t, int i)
 
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
 {
-    __shared__ float tau_rx[RTUS_TFM_RX_TILE][RTUS_BLOCK];           // 32 KB: 5 workgroups per CU
+    __shared__ float tau_rx[RTUS_TFM_RX_TILE][RTUS_BLOCK];           // 64 KB: 2 workgroups per CU; a 64-element receive
+                                                                      // aperture is ONE tile: the transmit delays are read once
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
         // Sixteen receive elements per trip: 16 independent gathers in flight per lane, ALL issued before the first is
         // consumed (two explicit phases: left to itself the scheduler pairs each load with its use).  An image of
         // 256 x 256 focal points is 1024 waves — one per SIMD — so nothing but the wave's own loads hides the ~1 us a
-        // gather takes: 4 in flight 441 us, 8: 282 us, 16: 214 us, 32 (two transmit elements at once): 218 us — from 16 on
+        // gather takes: 4 in flight 441 us, 8: 282 us, 16: 214 us (192 us with the whole receive aperture in one tile), 32 (two
+        // transmit elements at once): 218 us — from 16 on
         // the vector-memory address path binds (64 scattered 8-byte requests per wave-instruction, ~27 cycles each per CU).
         for (int tx = 0; tx < a.n_tx; ++tx) {
             const float tt = tfm_tau(a.tt_tx[(size_t)tx * nf + f], a.fs, a.half_t0s);
