@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUS_VERSION 101 /* 0.1.1 */
+#define RTUS_VERSION 102 /* 0.1.2: rtus_solve_workspace_bytes takes n_rx */
 
 typedef enum rtus_status {
     RTUS_OK = 0,
@@ -147,7 +147,7 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
  * ---------------------------------------------------------------------------------------- */
 #define RTUS_MAX_ROOTS 4
 
-size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx);
+size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx);
 
 int rtus_solve_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,
                    const double *d_x_a, const double *d_z_a, int n_tx,

@@ -93,7 +93,7 @@ def lib():
     L.rtus_tfm.argtypes = [dp, ip, ip, ip, C.c_double, C.c_double, dp, dp, ip, dp, ip]
     for name in ("rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm"):
         getattr(L, name).restype = ip
-    L.rtus_solve_workspace_bytes.argtypes = [ip, ip, ip]
+    L.rtus_solve_workspace_bytes.argtypes = [ip, ip, ip, ip]
     L.rtus_solve_workspace_bytes.restype = C.c_size_t
     L.rtus_solve_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, ip, dp, ip, C.c_double, dp, dp, dp, dp, vp, vp, C.c_size_t,
                                  C.c_uint, vp]

@@ -14,7 +14,7 @@ hipError_t rtus_launch_shoot(const rtus_lens& lens, const double* geoms, int n_g
                              const double* z_a, int n_tx, const double* alpha, const double* z_f, int n,
                              double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
                              void* ws, unsigned flags, hipStream_t s);
-size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx);
+size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx, int n_rx);
 hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                              const double* z_a, int n_tx, const double* alpha, int n, const double* x_rx, int n_rx,
                              double z_land, double* tt, double* alpha_root, double* tt_all,
@@ -315,9 +315,9 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
 }
 
 // ---------------------------------------------------------------------------- root-finding solve
-size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx)
+size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx)
 {
-    return (n_rays > 0 && n_geom > 0 && n_tx > 0) ? rtus_solve_ws_bytes(n_rays, n_geom, n_tx) : 0;
+    return (n_rays > 0 && n_geom > 0 && n_tx > 0 && n_rx > 0) ? rtus_solve_ws_bytes(n_rays, n_geom, n_tx, n_rx) : 0;
 }
 
 static int check_solve(const rtus_lens* lens, const void* geoms, int n_geom, const void* x_a, const void* z_a, int n_tx,
@@ -340,7 +340,7 @@ int rtus_solve_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, con
 {
     int st = check_solve(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt, flags);
     if (st) return st;
-    if (!d_workspace || ((uintptr_t)d_workspace & 63) || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx)) return RTUS_ERR_WORKSPACE;
+    if (!d_workspace || ((uintptr_t)d_workspace & 63) || workspace_bytes < rtus_solve_ws_bytes(n_rays, n_geom, n_tx, n_rx)) return RTUS_ERR_WORKSPACE;
     LAUNCH_TRY(rtus_launch_solve(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, n_rays, d_x_rx, n_rx, z_land, d_tt,
                               d_alpha_root, d_tt_all, d_alpha_all, d_n_roots, d_workspace, flags, (hipStream_t)stream));
     return RTUS_OK;
@@ -353,7 +353,7 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     int st = check_solve(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, n_rays, x_rx, n_rx, z_land, tt, flags);
     if (st) return st;
     const size_t tot = (size_t)n_geom * n_tx * n_rx;
-    const size_t wsb = rtus_solve_ws_bytes(n_rays, n_geom, n_tx);
+    const size_t wsb = rtus_solve_ws_bytes(n_rays, n_geom, n_tx, n_rx);
     const size_t need = al256(16 * (size_t)n_geom) + 2 * al256(8 * (size_t)n_tx) + al256(8 * (size_t)n_rays) + al256(8 * (size_t)n_rx) +
                         al256(wsb) + al256(8 * tot) + (alpha_root ? al256(8 * tot) : 0) +
                         (tt_all ? al256(8 * tot * RTUS_MAX_ROOTS) : 0) + (alpha_all ? al256(8 * tot * RTUS_MAX_ROOTS) : 0) +

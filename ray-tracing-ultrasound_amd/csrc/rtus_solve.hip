@@ -1,0 +1,371 @@
+// rtus_solve.hip — pulse-echo travel times by root-finding x_land(alpha) = x_rx (the north-star's replacement for the
+// reference's grid scan + tolerance matcher, main_rt.py:479-501).  Its own translation unit because it is compiled with
+// -mllvm -disable-machine-licm (Makefile): the iteration is a LOOP around trace_ray, and the machine-level loop-invariant
+// code motion hoists the ~60 64-bit literals and scalar table loads of the trigonometric kernels out of it — 242 VGPRs
+// and 110 spilled SGPRs; without the hoisting 123 VGPRs and nothing in scratch.
+#include "rtus_trace.h"
+
+// ---- pulse-echo root-finding solve ------------------------------------------------------------
+// The reference matches elements to whichever GRID ray happens to land within a tolerance
+// (main_rt.py:487-501).  Here x_land(alpha) = x_rx is solved: the grid trace (rtus_shoot_kernel)
+// only brackets the roots — consecutive finite grid rays whose landing points straddle the element —
+// and each bracket is refined by a bracketed interpolation iteration, every evaluation being a
+// full trace_ray at that lane's own alpha.  x_land(alpha) is U-shaped, so an element usually has two
+// ray paths; all (up to RTUS_MAX_ROOTS) are returned in ascending alpha, plus the least-time one.
+//
+// One kernel, three phases per workgroup (RTUS_SOLVE_WAVES wave-tasks = that many (row, 64-element chunk) pairs):
+//   A  brackets: lanes = rx elements of the task's row.  MASKS (apertures up to RTUS_SOLVE_MASK_MAX_RX elements): the grid
+//      trace has already asked the question pair by pair (rtus_shoot_kernel<., true>) — the lane reads one 64-bit mask per
+//      64-ray block and takes its set bits in ascending order, plus the pair that straddles two blocks.  Otherwise: a
+//      lock-step scan of the row's landing points (wave-uniform index -> scalar loads; 64-ray blocks that cannot bracket
+//      any of the wave's elements are skipped through the (min, max) intervals the grid trace left behind).  Either way up
+//      to four brackets per element, in ascending alpha;
+//   B  the workgroup's brackets are compacted into ONE list in LDS (wave prefix by ballots, the wave bases after a
+//      barrier): an element of the reference's aperture has 0.6 brackets on average, so lanes = elements would leave
+//      most lanes idle through every trace_ray — and would refine an element's brackets one after another;
+//   C  waves take 64 list entries at a time: lanes = brackets, all refined together (different rows in one wave:
+//      the per-row inputs are per-lane values here);
+//   D  after a barrier the element lanes of phase A collect their roots from LDS (ascending alpha, compacted).
+// The iteration (scripts/proto_solve_iter.c, CPU model on the reference sweep's 40,459 brackets): start = inverse
+// quadratic interpolation through the bracket's two grid rays and the neighbouring grid ray on the side of the smaller
+// residual; then inverse quadratic interpolation through the three latest points, secant / bisection as the safeguard
+// (candidate outside the bracket, or |f| not halved); a lane stops when |f| <= 1e-13 m, or — from its second evaluation
+// on — when |f| <= 1e-9 m and the interpolation step it would take next is below 1e-8 rad: that step is NOT taken but
+// applied to alpha and (linearly, through the two latest evaluations) to T; what is left is third order.  2.01
+// evaluations per bracket (Illinois, round 2: 3.92) and 99.3 % of the brackets done after two — which matters more than
+// the mean: a wave iterates until its slowest lane is done; |dT| <= 4e-15 s against bisection, the same root / no-root
+// decisions on all of them.
+#ifndef RTUS_SOLVE_WAVES
+#define RTUS_SOLVE_WAVES 4
+#endif
+#define RTUS_SOLVE_TPB (RTUS_SOLVE_WAVES * 64)
+#ifndef RTUS_SOLVE_MIN_WAVES
+#define RTUS_SOLVE_MIN_WAVES 5
+#endif
+struct SolveArgs {
+    ShootArgs s;                        // lens, geometry, tx, polyline + boxes, flags
+    const double* __restrict__ alpha;   // [n]  grid
+    const double* __restrict__ land_x;  // [rows][n] landing x of the grid rays on z = z_land
+    const double2* __restrict__ land_box;  // [rows][nb] (min, max) of the finite landing x of rays 64B .. 64B+63 (scan mode)
+    const unsigned long long* __restrict__ pair_mask;   // [rows][nb][rx_pad] (mask mode), see ShootArgs
+    int nb, rx_pad;
+    const double* __restrict__ x_rx;    // [n_rx]
+    double z_land;
+    int n_rx, chunks;                   // chunks = ceil(n_rx / 64)
+    long long n_tasks;                  // rows * chunks
+    double* __restrict__ tt;            // [rows][n_rx] least-time root (NaN: none)
+    double* __restrict__ alpha_root;    // nullable, its launch angle
+    double* __restrict__ tt_all;        // nullable [rows][n_rx][RTUS_MAX_ROOTS]
+    double* __restrict__ alpha_all;     // nullable [rows][n_rx][RTUS_MAX_ROOTS]
+    uint8_t* __restrict__ n_roots;      // nullable [rows][n_rx]
+};
+
+// 1 / v to ~1e-15 (the iteration only forms candidates with it)
+__device__ __forceinline__ double solve_rcp(double v)
+{
+    double y = __builtin_amdgcn_rcp(v);
+    y = fma(y, fma(-v, y, 1.0), y);
+    return fma(y, fma(-v, y, 1.0), y);
+}
+// inverse quadratic interpolation to f = 0 through (xa, fa), (xb, fb), (xc, fc), relative to xa
+__device__ __forceinline__ double solve_iqi(double xa, double fa, double xb, double fb, double xc, double fc)
+{
+    const double db = xb - xa, dc = xc - xa;
+    const double q = solve_rcp((fb - fa) * (fb - fc) * (fc - fa));
+    // db fa fc / ((fb-fa)(fb-fc)) + dc fa fb / ((fc-fa)(fc-fb)) over the common denominator
+    return xa + fa * q * (db * fc * (fc - fa) - dc * fb * (fb - fa));
+}
+
+template <bool FAST, bool MASKS>
+__global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(RTUS_SOLVE_MIN_WAVES, 8))) void rtus_solve_kernel(SolveArgs q)
+{
+    __shared__ unsigned items[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];        // (slot << 2 | k) is implied by position: see below
+    __shared__ int item_r[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
+    __shared__ double res_t[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS], res_a[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
+    __shared__ int wave_tot[RTUS_SOLVE_WAVES];
+    const ShootArgs& a = q.s;
+    const LensK& k = a.k;
+    const int n = a.n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // ---- A: bracket scan -----------------------------------------------------------------------------------------
+    const long long task = (long long)blockIdx.x * RTUS_SOLVE_WAVES + wv;
+    const bool task_live = task < q.n_tasks;                           // wave-uniform
+    const long long t_row = task_live ? task / q.chunks : 0;
+    const int chunk = task_live ? (int)(task - t_row * q.chunks) : 0;
+    const int e_raw = chunk * 64 + lane;
+    const bool live = task_live && e_raw < q.n_rx;
+    const int e = min(e_raw, q.n_rx - 1);
+    const double xe = q.x_rx[e];
+    int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
+    auto add_bracket = [&](bool yes, int r) {
+        if (yes) {
+            b0 = cnt == 0 ? r : b0; b1 = cnt == 1 ? r : b1;
+            b2 = cnt == 2 ? r : b2; b3 = cnt == 3 ? r : b3;
+            ++cnt;
+        }
+    };
+    if (MASKS && task_live) {
+        const double* __restrict__ lrow = q.land_x + (size_t)t_row * n;
+        const unsigned long long* __restrict__ mrow = q.pair_mask + (size_t)t_row * q.nb * q.rx_pad + e_raw;   // e_raw < rx_pad
+        for (int B0 = 0; B0 < q.nb; B0 += 4) {                          // four blocks per trip: their loads are in flight together
+            unsigned long long m[4];
+            double la[4], lb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int B = min(B0 + i, q.nb - 1);
+                m[i] = B0 + i < q.nb ? mrow[(size_t)B * q.rx_pad] : 0ull;
+                la[i] = lrow[min(B * 64 + 63, n - 1)]; lb[i] = lrow[min(B * 64 + 64, n - 1)];   // the pair that straddles blocks B, B + 1
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rb = (B0 + i) * 64;
+                while (__any(m[i] != 0ull)) {                           // set bits in ascending order
+                    const bool has = m[i] != 0ull;
+                    add_bracket(has, rb + (int)__builtin_ctzll(has ? m[i] : 1ull));
+                    m[i] &= m[i] - 1ull;
+                }
+                const bool edge = rb + 64 < n && isfinite(la[i]) && isfinite(lb[i]) &&
+                                  ((la[i] < xe && xe <= lb[i]) || (la[i] > xe && xe >= lb[i]));
+                add_bracket(edge, rb + 63);
+            }
+        }
+    }
+    if (!MASKS && task_live) {
+        const double* __restrict__ lrow = q.land_x + (size_t)t_row * n;
+        // the wave's elements span [xe_lo, xe_hi]; a 64-pair block of grid rays whose landing points all lie
+        // outside that span cannot bracket any of them and is skipped (wave-uniform decision, scalar loads)
+        double xe_lo = xe, xe_hi = xe;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { xe_lo = fmin(xe_lo, __shfl_xor(xe_lo, o)); xe_hi = fmax(xe_hi, __shfl_xor(xe_hi, o)); }
+        const double2* __restrict__ brow = q.land_box + (size_t)t_row * q.nb;
+        for (int B = 0; B < q.nb; ++B) {
+            // pairs (r - 1, r) for r = max(64 B, 1) .. 64 B + 63: the block's own rays and the last ray of the block before
+            const double2 bx = brow[B];
+            const int rb = B * 64;
+            const double lprev = lrow[max(rb - 1, 0)];
+            const double lo = fmin(bx.x, isfinite(lprev) ? lprev : INFINITY), hi = fmax(bx.y, isfinite(lprev) ? lprev : -INFINITY);
+            if (lo > xe_hi || hi < xe_lo || !(lo <= hi)) continue;
+            double fprev = lprev - xe;
+            for (int r0 = max(rb, 1); r0 <= min(rb + 63, n - 1); r0 += 8) {      // 8 grid rays per trip: one batch of scalar loads
+                double lx[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lx[i] = lrow[min(r0 + i, n - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = r0 + i;
+                    const double fcur = lx[i] - xe;
+                    const bool in = r < n && r <= rb + 63;
+                    const bool st = in && isfinite(fprev) && isfinite(fcur) &&
+                                    ((fprev < 0.0 && fcur >= 0.0) || (fprev > 0.0 && fcur <= 0.0));
+                    add_bracket(st, r - 1);
+                    fprev = in ? fcur : fprev;
+                }
+            }
+        }
+    }
+    cnt = live ? min(cnt, RTUS_MAX_ROOTS) : 0;
+
+    // ---- B: one list of brackets per workgroup, in (wave, element, bracket) order ---------------------------------------
+    // position of a lane's first bracket inside its wave: sum over j of the lanes below it that own a (j+1)-th bracket
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        const lanemask mj = __ballot(cnt > j);
+        pre += __builtin_amdgcn_mbcnt_hi((unsigned)(mj >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mj, 0));
+        tot += __popcll(mj);
+    }
+    if (lane == 0) wave_tot[wv] = tot;
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) { res_t[threadIdx.x * RTUS_MAX_ROOTS + j] = NAN; res_a[threadIdx.x * RTUS_MAX_ROOTS + j] = NAN; }
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < RTUS_SOLVE_WAVES; ++w) { const int tw = wave_tot[w]; base += w < wv ? tw : 0; total += tw; }
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        if (j < cnt) {
+            items[base + pre + j] = (unsigned)threadIdx.x * RTUS_MAX_ROOTS + j;      // the result slot: (wave, lane, bracket)
+            item_r[base + pre + j] = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+        }
+    }
+    __syncthreads();
+
+    // ---- C: lanes = brackets ---------------------------------------------------------------------------------------------
+    for (int i0 = wv * 64; i0 < total; i0 += RTUS_SOLVE_TPB) {          // wave-uniform
+        const bool mine = i0 + lane < total;
+        const int ii = min(i0 + lane, total - 1);                       // idle lanes redo the last bracket (no store)
+        const unsigned slot = items[ii];
+        const int br = item_r[ii];
+        const int sw = (int)(slot >> 8), sl = (int)((slot >> 2) & 63);  // (RTUS_MAX_ROOTS = 4: slot = ((wave * 64) + lane) * 4 + k)
+        const long long itask = (long long)blockIdx.x * RTUS_SOLVE_WAVES + sw;
+        const long long row = itask / q.chunks;
+        const int ie = (int)(itask - row * q.chunks) * 64 + sl;
+        const int g = (int)(row / a.n_tx), tx = (int)(row - (long long)g * a.n_tx);
+        const double xr = q.x_rx[ie];
+        const double* __restrict__ lrow = q.land_x + (size_t)row * n;
+        RayIn in;
+        in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];
+        in.xa = a.x_a[tx]; in.za = a.z_a[tx]; in.zf = q.z_land;
+        double xlo = q.alpha[br], xhi = q.alpha[br + 1];
+        double flo = lrow[br] - xr, fhi = lrow[br + 1] - xr;
+        // third grid ray for the first candidate: the neighbour on the side of the smaller residual, else the other one
+        double xt, ft;
+        {
+            const bool left = fabs(flo) < fabs(fhi);
+            const int t1 = left ? br - 1 : br + 2, t2 = left ? br + 2 : br - 1;
+            const int c1 = min(max(t1, 0), n - 1), c2 = min(max(t2, 0), n - 1);
+            const double l1 = lrow[c1], l2 = lrow[c2];
+            const bool ok1 = c1 == t1 && isfinite(l1), ok2 = c2 == t2 && isfinite(l2);
+            xt = q.alpha[ok1 ? c1 : c2];
+            ft = (ok1 ? l1 : (ok2 ? l2 : NAN)) - xr;
+        }
+        // fhi == 0: the grid ray itself is the root; both ends within 1e-13 m already (x_land is flat to rounding there:
+        // the centre element over a centred pipe, tangent hits): the end nearer to zero — one evaluation either way
+        const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
+        double cand = solve_iqi(xlo, flo, xhi, fhi, xt, ft);             // NaN without a third ray
+        if (!(cand > xlo && cand < xhi)) cand = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
+        if (!(cand > xlo && cand < xhi)) cand = 0.5 * (xlo + xhi);
+        if (single) cand = (fhi == 0.0 || fabs(fhi) < fabs(flo)) ? xhi : xlo;
+        double x1 = xhi, f1 = fhi, x2 = xlo, f2 = flo;                   // the two latest points besides the current one
+        double xp = NAN, fp = NAN, Tp = NAN;                             // the previous EVALUATED point
+        double fprev_abs = INFINITY;
+        double x_fin = NAN, T_fin = NAN, f_fin = NAN;
+        bool done = false, dead = false;
+        int nev = 0;
+        for (int it = 0; it < 64; ++it) {
+            if (!__any(!done)) break;
+            const double ac = cand;                                      // a finished lane re-traces its last point: same bits, ignored
+            double sn, cs, px, pz, dz, dx;
+            rtus_sincos(ac, sn, cs);                                     // |alpha| < 8: the bounded-range kernels
+            lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
+            in.P = make_double2(px, pz);
+            if (FAST) { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+            else in.phis = rtus_atan2(dz, dx);
+            RayOut o;
+            trace_ray<FAST>(a, in, o);                                   // all 64 lanes together
+            const double fc = o.x_in - xr;
+            const double t1 = seg_time<FAST>(in.xa, in.za, px, pz, k.c1, k.inv_c1);
+            const double t2 = seg_time<FAST>(px, pz, o.xq, o.zq, k.c2, k.inv_c2);
+            const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
+            const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
+            const double T = ((t1 + t2) + t3) + t4;
+            if (!done) {
+                ++nev;
+                if (!isfinite(fc)) { dead = true; done = true; }         // the branch ends inside the bracket
+                else {
+                    // the step the iteration would take next: inverse quadratic interpolation through the three latest
+                    // points (secant when that misbehaves) — taken as the next candidate, or, once the residual is small,
+                    // NOT taken but applied to alpha and T: what is left is third order in the distances of the three points
+                    double c1 = solve_iqi(ac, fc, x1, f1, x2, f2);
+                    const double c2 = ac - fc * (ac - x1) * solve_rcp(fc - f1);
+                    if (!(fabs(c1 - ac) <= 2.0 * fabs(c2 - ac))) c1 = c2;
+                    double step = c1 - ac;
+                    step = (fabs(step) <= (nev >= 2 ? 1e-8 : 1e-10) && fc != 0.0) ? step : 0.0;   // NaN -> 0
+                    const bool stop = single || fabs(fc) <= 1e-13 || (xhi - xlo) <= 1e-13 ||
+                                      (step != 0.0 && fabs(fc) <= (nev >= 2 ? 1e-9 : 1e-11));
+                    if (stop) {
+                        done = true;
+                        f_fin = fc;
+                        x_fin = single ? ac : ac + step;
+                        // T is smooth in alpha: linear through the two latest evaluations (first evaluation: the step is
+                        // below 1e-10 rad, |dT/dalpha| ~ 1e-5 s/rad)
+                        T_fin = (nev >= 2 && !single && step != 0.0) ? T + (T - Tp) * solve_rcp(ac - xp) * step : T;
+                    } else {
+                        if ((fc < 0.0) == (flo < 0.0)) { xlo = ac; flo = fc; } else { xhi = ac; fhi = fc; }
+                        if (!(c1 > xlo && c1 < xhi)) c1 = c2;
+                        if (!(c1 > xlo && c1 < xhi) || fabs(fc) > 0.5 * fprev_abs) c1 = 0.5 * (xlo + xhi);
+                        cand = c1;
+                        fprev_abs = fabs(fc);
+                        xp = ac; fp = fc; Tp = T;
+                        x2 = x1; f2 = f1; x1 = ac; f1 = fc;
+                    }
+                }
+            }
+        }
+        if (!done) { x_fin = xp; f_fin = fp; T_fin = Tp; }              // iteration cap: the last point evaluated
+        const bool root = !dead && fabs(f_fin) < 1e-9;                   // |f| large at convergence: a jump, not a root
+        if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
+    }
+    __syncthreads();
+
+    // ---- D: the element lanes collect their roots (ascending alpha, compacted) ---------------------------------------------
+    if (!live) return;
+    double tmin = NAN, amin = NAN, tk[RTUS_MAX_ROOTS], ak[RTUS_MAX_ROOTS];
+    int nr = 0;
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) { tk[j] = NAN; ak[j] = NAN; }
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        const double T = res_t[threadIdx.x * RTUS_MAX_ROOTS + j], A = res_a[threadIdx.x * RTUS_MAX_ROOTS + j];
+        if (T == T) {
+            tk[0] = nr == 0 ? T : tk[0]; ak[0] = nr == 0 ? A : ak[0];
+            tk[1] = nr == 1 ? T : tk[1]; ak[1] = nr == 1 ? A : ak[1];
+            tk[2] = nr == 2 ? T : tk[2]; ak[2] = nr == 2 ? A : ak[2];
+            tk[3] = nr == 3 ? T : tk[3]; ak[3] = nr == 3 ? A : ak[3];
+            if (!(tmin <= T)) { tmin = T; amin = A; }
+            ++nr;
+        }
+    }
+    const size_t o1 = (size_t)t_row * q.n_rx + e;
+    q.tt[o1] = tmin;
+    if (q.alpha_root) q.alpha_root[o1] = amin;
+    if (q.n_roots) q.n_roots[o1] = (uint8_t)nr;
+#pragma unroll
+    for (int kk = 0; kk < RTUS_MAX_ROOTS; ++kk) {
+        if (q.tt_all) q.tt_all[o1 * RTUS_MAX_ROOTS + kk] = tk[kk];
+        if (q.alpha_all) q.alpha_all[o1 * RTUS_MAX_ROOTS + kk] = ak[kk];
+    }
+}
+
+// Workspace of the solve = shoot workspace + land_x[rows][n] + land intervals[rows][nb].
+static size_t sws_land_off(int n) { return align32(shoot_ws_bytes(n)); }
+static size_t sws_box_off(int n, int n_geom, int n_tx) { return align32(sws_land_off(n) + (size_t)n_geom * n_tx * (size_t)n * sizeof(double)); }
+// after the landing points: the pair masks [rows][nb][rx_pad] (apertures up to RTUS_SOLVE_MASK_MAX_RX) or the landing intervals [rows][nb]
+size_t rtus_solve_ws_bytes(int n, int n_geom, int n_tx, int n_rx)
+{
+    const size_t per_block = n_rx <= RTUS_SOLVE_MASK_MAX_RX ? (size_t)((n_rx + 63) & ~63) * sizeof(unsigned long long) : sizeof(double2);
+    return sws_box_off(n, n_geom, n_tx) + (size_t)n_geom * n_tx * (size_t)((n + 63) / 64) * per_block;
+}
+
+// Four launches: polyline, box records, grid trace (landing points + which elements each ray pair brackets), refine.
+hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
+                             const double* z_a, int n_tx, const double* alpha, int n, const double* x_rx, int n_rx,
+                             double z_land, double* tt, double* alpha_root, double* tt_all,
+                             double* alpha_all, uint8_t* n_roots, void* ws, unsigned flags, hipStream_t s)
+{
+    char* w = (char*)ws;
+    double* land = (double*)(w + sws_land_off(n));
+    const bool masks = n_rx <= RTUS_SOLVE_MASK_MAX_RX;
+    double2* boxes = masks ? nullptr : (double2*)(w + sws_box_off(n, n_geom, n_tx));
+    unsigned long long* pmask = masks ? (unsigned long long*)(w + sws_box_off(n, n_geom, n_tx)) : nullptr;
+    // 1. grid trace with z_f = z_land for every ray (+ which elements each pair of consecutive rays brackets)
+    hipError_t e = rtus_launch_shoot_ex(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, nullptr, z_land, n, nullptr, nullptr,
+                                        nullptr, land, nullptr, boxes, pmask, masks ? x_rx : nullptr, masks ? n_rx : 0, ws, flags, s);
+    if (e != hipSuccess) return e;
+    // 2. bracket + refine
+    SolveArgs q;
+    ShootArgs& a = q.s;
+    a.k = make_lens_k(lens);
+    a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = nullptr; a.zf_const = z_land;
+    shoot_args_workspace(a, w, n);
+    a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0;
+    a.n_tx = n_tx; a.n_geom = n_geom;
+    a.flags = flags;
+    q.alpha = alpha; q.land_x = land; q.land_box = boxes; q.pair_mask = pmask; q.rx_pad = (n_rx + 63) & ~63; q.nb = (n + 63) / 64; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
+    q.chunks = (n_rx + 63) / 64;
+    q.n_tasks = (long long)n_geom * n_tx * q.chunks;
+    q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
+    const long long blocks = (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
+    if (masks) {
+        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+        else hipLaunchKernelGGL((rtus_solve_kernel<false, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+    } else {
+        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, false>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+        else hipLaunchKernelGGL((rtus_solve_kernel<false, false>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+    }
+    return hipGetLastError();
+}

@@ -55,6 +55,40 @@ class ShootPlan:
         return o
 
 
+class SolvePlan:
+    """Pre-allocated workspace + outputs for repeated root-finding solves of one shape (rtus_solve_dev): no allocation,
+    no sync inside ``run`` — capturable in a hipGraph.  tt / alpha_root [G, T, E]; with all_roots also tt_all / alpha_all
+    [G, T, E, 4] and n_roots [G, T, E]."""
+
+    def __init__(self, n_geom, n_tx, n_rays, n_rx, *, params: Params = None, fast=False, true_tangent=False,
+                 analytic_lens=False, all_roots=False, device="cuda"):
+        self.p = _resolve(params)
+        self.G, self.T, self.N, self.E = int(n_geom), int(n_tx), int(n_rays), int(n_rx)
+        self.ws_bytes = int(_lib.lib().rtus_solve_workspace_bytes(self.N, self.G, self.T, self.E))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        G, T, E = self.G, self.T, self.E
+        f64 = dict(dtype=torch.float64, device=device)
+        self.out = {"tt": torch.empty((G, T, E), **f64), "alpha_root": torch.empty((G, T, E), **f64)}
+        if all_roots:
+            self.out.update(tt_all=torch.empty((G, T, E, 4), **f64), alpha_all=torch.empty((G, T, E, 4), **f64),
+                            n_roots=torch.empty((G, T, E), dtype=torch.uint8, device=device))
+        self.lens = self.p.lens()
+        self.flags = (1 if fast else 0) | (2 if true_tangent else 0) | (4 if analytic_lens else 0)
+
+    def run(self, geoms, x_a, z_a, alpha, x_rx, z_land=None):
+        _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(x_rx, "x_rx")
+        if geoms.shape != (self.G, 2) or x_a.numel() != self.T or z_a.numel() != self.T \
+                or alpha.numel() != self.N or x_rx.numel() != self.E:
+            raise ValueError("tensor shapes do not match the plan")
+        o = self.out
+        st = _lib.lib().rtus_solve_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha), self.N,
+                                       _p(x_rx), self.E, float(self.p.d if z_land is None else z_land), _p(o["tt"]),
+                                       _p(o["alpha_root"]), _p(o.get("tt_all")), _p(o.get("alpha_all")), _p(o.get("n_roots")),
+                                       _p(self.ws), self.ws_bytes, self.flags, _stream())
+        _lib.check(st, "rtus_solve_dev")
+        return o
+
+
 def match_dev(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, out=None):
     """land_x/tof [rows, N], x_rx [E] -> (first_ray i32[rows,E], hit u8[rows,E], tof_hit f64[rows,E])."""
     _chk(land_x, "land_x"); _chk(tof, "tof"); _chk(x_rx, "x_rx")
