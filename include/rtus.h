@@ -111,6 +111,11 @@ int rtus_selftest(const rtus_lens *lens, int n_rays, long long n_math, unsigned 
  *                           the alpha-grid polyline (main_rt.py:385-390) */
 #define RTUS_TRUE_PIPE_TANGENT 0x2u
 #define RTUS_ANALYTIC_LENS 0x4u
+/* Device entry points only (the host-buffer twins ignore it): the workspace already holds the lens polyline of THIS alpha
+ * grid, lens and n_rays — left there by a previous rtus_shoot_dev / rtus_solve_dev call on the same workspace — so the
+ * call skips rebuilding it.  The polyline depends on nothing else (main_rt.py:338: x_p, z_p = x_z_from_alpha(alpha)), and
+ * the reference's driver traces 210 geometries over one grid (main_rt.py:464-482). */
+#define RTUS_POLYLINE_READY 0x8u
 
 /* Device scratch of one call (polyline, tangents, bounding boxes and their depth-first records): 64-byte aligned
  * (hipMalloc gives 256), rebuilt by every call, not shared between calls that may run concurrently. */

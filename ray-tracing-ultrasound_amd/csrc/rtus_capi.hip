@@ -262,7 +262,7 @@ static int check_shoot(const rtus_lens* lens, const void* geoms, int n_geom, con
     if (!(lens->c1 > 0) || !(lens->c2 > 0) || lens->c1 == lens->c2) return RTUS_ERR_INVALID_ARG;
     return RTUS_OK;
 }
-#define RTUS_SHOOT_KNOWN_FLAGS (RTUS_SHOOT_FAST_MATH | RTUS_TRUE_PIPE_TANGENT | RTUS_ANALYTIC_LENS)
+#define RTUS_SHOOT_KNOWN_FLAGS (RTUS_SHOOT_FAST_MATH | RTUS_TRUE_PIPE_TANGENT | RTUS_ANALYTIC_LENS | RTUS_POLYLINE_READY)
 
 int rtus_shoot_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, const double* d_x_a,
                    const double* d_z_a, int n_tx, const double* d_alpha, const double* d_z_f, int n_rays,
@@ -304,7 +304,7 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     double* lx = land_x ? S.take<double>(rn) : nullptr;
     uint8_t* sb = status ? S.take<uint8_t>(rn) : nullptr;
     HIP_TRY(S.flush());
-    LAUNCH_TRY(rtus_launch_shoot(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, o8, t4, tt, lx, sb, ws, flags, S.a->stream));
+    LAUNCH_TRY(rtus_launch_shoot(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, o8, t4, tt, lx, sb, ws, flags & ~RTUS_POLYLINE_READY, S.a->stream));
     S.download(out8, o8, 8 * rn);
     S.download(tof4, t4, 4 * rn);
     S.download(tof, tt, rn);
@@ -373,8 +373,8 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     double* daa = alpha_all ? S.take<double>(tot * RTUS_MAX_ROOTS) : nullptr;
     uint8_t* dn = n_roots ? S.take<uint8_t>(tot) : nullptr;
     HIP_TRY(S.flush());
-    LAUNCH_TRY(rtus_launch_solve(*lens, g, n_geom, xa, za, n_tx, al, n_rays, rx, n_rx, z_land, dt, da, dta, daa, dn, ws, flags,
-                              S.a->stream));
+    LAUNCH_TRY(rtus_launch_solve(*lens, g, n_geom, xa, za, n_tx, al, n_rays, rx, n_rx, z_land, dt, da, dta, daa, dn, ws,
+                              flags & ~RTUS_POLYLINE_READY, S.a->stream));
     S.download(tt, dt, tot);
     S.download(alpha_root, da, tot);
     S.download(tt_all, dta, tot * RTUS_MAX_ROOTS);

@@ -35,16 +35,14 @@ __device__ __forceinline__ double4 make_box(double xmin, double xmax, double zmi
 }
 
 // ---- polyline + bounding-box hierarchy -------------------------------------------------------
-__global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, const double* __restrict__ alpha,
-                                                                     int n, double2* __restrict__ curve,
-                                                                     double* __restrict__ phi_s,
-                                                                     double2* __restrict__ tan_u,
-                                                                     double4* __restrict__ node0,
-                                                                     double4* __restrict__ node1,
-                                                                     double4* __restrict__ node2)
+// One polyline point per thread; `part` = which 512-point box (node2) the thread's group of 512 threads builds, `t` = the thread's
+// index inside it.  Called by every thread of the group (it contains a barrier).
+__device__ __forceinline__ void curve_part(const LensK& k, const double* __restrict__ alpha, int n, double2* __restrict__ curve,
+                                           double* __restrict__ phi_s, double2* __restrict__ tan_u, double4* node0,
+                                           double4* node1, double4* node2, int part, int t,
+                                           double (*red)[RTUS_CURVE_TPB / 64])
 {
-    __shared__ double red[4][RTUS_CURVE_TPB / 64];
-    const int j = blockIdx.x * RTUS_CURVE_TPB + threadIdx.x;
+    const int j = part * RTUS_CURVE_TPB + t;
     double x = 0, z = 0, dz, dx;
     const bool live = j < n;
     if (live) {
@@ -63,29 +61,39 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
         xmax = fmax(xmax, __shfl_xor(xmax, o));
         zmin = fmin(zmin, __shfl_xor(zmin, o));
         zmax = fmax(zmax, __shfl_xor(zmax, o));
-        if (o == 4 && (threadIdx.x & 7) == 0 && live) node0[j >> 3] = make_box(xmin, xmax, zmin, zmax);
+        if (o == 4 && (t & 7) == 0 && live) node0[j >> 3] = make_box(xmin, xmax, zmin, zmax);
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = t & 63, wv = t >> 6;
     if (lane == 0) {
         if (live) node1[j >> 6] = make_box(xmin, xmax, zmin, zmax);
         red[0][wv] = xmin; red[1][wv] = xmax; red[2][wv] = zmin; red[3][wv] = zmax;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t == 0 && part * RTUS_CURVE_TPB < n) {
         for (int w = 1; w < RTUS_CURVE_TPB / 64; ++w) {
             xmin = fmin(xmin, red[0][w]); xmax = fmax(xmax, red[1][w]);
             zmin = fmin(zmin, red[2][w]); zmax = fmax(zmax, red[3][w]);
         }
-        node2[blockIdx.x] = make_box(xmin, xmax, zmin, zmax);
+        node2[part] = make_box(xmin, xmax, zmin, zmax);
     }
 }
 
-__global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double4* __restrict__ node1,
-                                 const double4* __restrict__ node2, int n0, int n1, int n2, int n3,
-                                 TreeNode* __restrict__ tree)
+__global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, const double* __restrict__ alpha,
+                                                                     int n, double2* __restrict__ curve,
+                                                                     double* __restrict__ phi_s,
+                                                                     double2* __restrict__ tan_u,
+                                                                     double4* __restrict__ node0,
+                                                                     double4* __restrict__ node1,
+                                                                     double4* __restrict__ node2)
+{
+    __shared__ double red[4][RTUS_CURVE_TPB / 64];
+    curve_part(k, alpha, n, curve, phi_s, tan_u, node0, node1, node2, blockIdx.x, threadIdx.x, red);
+}
+
+__device__ __forceinline__ void tree_record(const double4* node0, const double4* node1, const double4* node2, int n0, int n1, int n2,
+                                            int n3, TreeNode* tree, int id)
 {
     const int total = n0 + n1 + n2 + n3;
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     int L, k;
     const double4* src;
@@ -125,6 +133,29 @@ __global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double
         }
         tree[total] = e;
     }
+}
+
+__global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double4* __restrict__ node1,
+                                 const double4* __restrict__ node2, int n0, int n1, int n2, int n3,
+                                 TreeNode* __restrict__ tree)
+{
+    tree_record(node0, node1, node2, n0, n1, n2, n3, tree, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Polylines of up to 1024 points (the reference's 905): polyline, boxes and records by ONE workgroup in ONE launch — a launch
+// of a few hundred threads costs ~5 us whatever it does, and the reference's calling pattern is many small calls.
+#define RTUS_GEOM1_TPB (2 * RTUS_CURVE_TPB)
+__global__ __launch_bounds__(RTUS_GEOM1_TPB) void rtus_geom1_kernel(LensK k, const double* __restrict__ alpha, int n,
+                                                                     double2* __restrict__ curve, double* __restrict__ phi_s,
+                                                                     double2* __restrict__ tan_u, double4* node0, double4* node1,
+                                                                     double4* node2, int n0, int n1, int n2, TreeNode* tree)
+{
+    __shared__ double red[2][4][RTUS_CURVE_TPB / 64];
+    const int part = threadIdx.x / RTUS_CURVE_TPB;
+    curve_part(k, alpha, n, curve, phi_s, tan_u, node0, node1, node2, part, threadIdx.x % RTUS_CURVE_TPB, red[part]);
+    __threadfence();                               // the boxes are read back from global memory (no __restrict__ on them here)
+    __syncthreads();
+    tree_record(node0, node1, node2, n0, n1, n2, 0, tree, threadIdx.x);
 }
 
 // ---- the forward trace: one ray of the alpha grid per lane --------------------------------------
@@ -244,6 +275,22 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
 // ---- host-side launchers (called from rtus_capi.hip) -----------------------------------------
 size_t rtus_ws_bytes(int n) { return shoot_ws_bytes(n); }
 
+// polyline + boxes + depth-first records of the alpha grid into the workspace `a` points to
+static void rtus_launch_geometry(const ShootArgs& a, const double* alpha, hipStream_t s)
+{
+    const int n = a.n;
+    if (n <= RTUS_GEOM1_TPB) {
+        hipLaunchKernelGGL(rtus_geom1_kernel, dim3(1), dim3(RTUS_GEOM1_TPB), 0, s, a.k, alpha, n, (double2*)a.curve, (double*)a.phi_s,
+                           (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1, (double4*)a.node2, a.n0, a.n1, a.n2, (TreeNode*)a.tree);
+        return;
+    }
+    hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
+                       (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
+                       (double4*)a.node2);
+    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
+                       a.n3, (TreeNode*)a.tree);
+}
+
 // z_f == nullptr: every ray lands on z = zf_const; land_box: optional per-wave (min, max) of the landing points (the solve)
 hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                                        const double* z_a, int n_tx, const double* alpha, const double* z_f, double zf_const, int n,
@@ -261,11 +308,7 @@ hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int 
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
     a.n_tx = n_tx; a.n_geom = n_geom;
     a.flags = flags;
-    hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
-                       (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
-                       (double4*)a.node2);
-    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
-                       a.n3, (TreeNode*)a.tree);
+    if (!(flags & RTUS_POLYLINE_READY)) rtus_launch_geometry(a, alpha, s);
     const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
     if (pair_mask) {
@@ -351,10 +394,7 @@ hipError_t rtus_selftest_run(const rtus_lens& lens, int n, long long n_math, uns
     for (int i = 0; i < n; ++i) alpha[i] = n > 1 ? -amax + 2.0 * amax * i / (n - 1) : 0.0;
     (void)hipMemcpyAsync(d_alpha, alpha.data(), sizeof(double) * n, hipMemcpyHostToDevice, s);
     shoot_args_workspace(a, w, n);
-    hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, d_alpha, n, (double2*)a.curve, (double*)a.phi_s,
-                       (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1, (double4*)a.node2);
-    hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
-                       a.n3, (TreeNode*)a.tree);
+    rtus_launch_geometry(a, d_alpha, s);
     std::vector<TreeNode> t(a.n_tree + 1);
     unsigned long long bad[2] = {0, 0};
     (void)hipMemcpyAsync(t.data(), a.tree, sizeof(TreeNode) * t.size(), hipMemcpyDeviceToHost, s);

@@ -35,6 +35,18 @@
 // evaluations per bracket (Illinois, round 2: 3.92) and 99.3 % of the brackets done after two — which matters more than
 // the mean: a wave iterates until its slowest lane is done; |dT| <= 4e-15 s against bisection, the same root / no-root
 // decisions on all of them.
+#ifdef RTUS_EXP_TIMING   // experiment builds only (scripts/exp_solve_timing.py): wall-clock stamps (100 MHz) per phase and wave
+__device__ unsigned long long rtus_solve_stamps[4096][16];
+#define STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x * RTUS_SOLVE_WAVES + (threadIdx.x >> 6) < 4096) \
+    rtus_solve_stamps[blockIdx.x * RTUS_SOLVE_WAVES + (threadIdx.x >> 6)][i] = wall_clock64(); } while (0)
+extern "C" int rtus_solve_stamps_read(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rtus_solve_stamps), sizeof(unsigned long long) * 4096 * 16);
+}
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #ifndef RTUS_SOLVE_WAVES
 #define RTUS_SOLVE_WAVES 4
 #endif
@@ -88,7 +100,8 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     const int n = a.n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
-    // ---- A: bracket scan -----------------------------------------------------------------------------------------
+    STAMP(0);
+    // ---- A: brackets -----------------------------------------------------------------------------------------------
     const long long task = (long long)blockIdx.x * RTUS_SOLVE_WAVES + wv;
     const bool task_live = task < q.n_tasks;                           // wave-uniform
     const long long t_row = task_live ? task / q.chunks : 0;
@@ -108,19 +121,21 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     if (MASKS && task_live) {
         const double* __restrict__ lrow = q.land_x + (size_t)t_row * n;
         const unsigned long long* __restrict__ mrow = q.pair_mask + (size_t)t_row * q.nb * q.rx_pad + e_raw;   // e_raw < rx_pad
-        for (int B0 = 0; B0 < q.nb; B0 += 4) {                          // four blocks per trip: their loads are in flight together
-            unsigned long long m[4];
-            double la[4], lb[4];
+        for (int B0 = 0; B0 < q.nb; B0 += 8) {                          // eight blocks per trip: their loads are in flight together
+            unsigned long long m[8];
+            double la[8], lb[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const int B = min(B0 + i, q.nb - 1);
                 m[i] = B0 + i < q.nb ? mrow[(size_t)B * q.rx_pad] : 0ull;
                 la[i] = lrow[min(B * 64 + 63, n - 1)]; lb[i] = lrow[min(B * 64 + 64, n - 1)];   // the pair that straddles blocks B, B + 1
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const int rb = (B0 + i) * 64;
-                while (__any(m[i] != 0ull)) {                           // set bits in ascending order
+                // set bits in ascending order, until every lane that still has some holds its four brackets (a centred pipe
+                // under the centre element lands every ray within rounding of the element: sign noise in half of all pairs)
+                while (__any(m[i] != 0ull && cnt < RTUS_MAX_ROOTS)) {
                     const bool has = m[i] != 0ull;
                     add_bracket(has, rb + (int)__builtin_ctzll(has ? m[i] : 1ull));
                     m[i] &= m[i] - 1ull;
@@ -165,6 +180,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         }
     }
     cnt = live ? min(cnt, RTUS_MAX_ROOTS) : 0;
+    STAMP(1);
 
     // ---- B: one list of brackets per workgroup, in (wave, element, bracket) order ---------------------------------------
     // position of a lane's first bracket inside its wave: sum over j of the lanes below it that own a (j+1)-th bracket
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
 
+    STAMP(2);
     // ---- C: lanes = brackets ---------------------------------------------------------------------------------------------
     for (int i0 = wv * 64; i0 < total; i0 += RTUS_SOLVE_TPB) {          // wave-uniform
         const bool mine = i0 + lane < total;
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         int nev = 0;
         for (int it = 0; it < 64; ++it) {
             if (!__any(!done)) break;
+            STAMP(3 + min(it, 9));
             const double ac = cand;                                      // a finished lane re-traces its last point: same bits, ignored
             double sn, cs, px, pz, dz, dx;
             rtus_sincos(ac, sn, cs);                                     // |alpha| < 8: the bounded-range kernels
@@ -287,7 +305,9 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         const bool root = !dead && fabs(f_fin) < 1e-9;                   // |f| large at convergence: a jump, not a root
         if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
     }
+    STAMP(13);
     __syncthreads();
+    STAMP(14);
 
     // ---- D: the element lanes collect their roots (ascending alpha, compacted) ---------------------------------------------
     if (!live) return;
@@ -316,6 +336,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         if (q.tt_all) q.tt_all[o1 * RTUS_MAX_ROOTS + kk] = tk[kk];
         if (q.alpha_all) q.alpha_all[o1 * RTUS_MAX_ROOTS + kk] = ak[kk];
     }
+    STAMP(15);
 }
 
 // Workspace of the solve = shoot workspace + land_x[rows][n] + land intervals[rows][nb].
@@ -360,12 +381,9 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks);
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
-    if (masks) {
-        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
-        else hipLaunchKernelGGL((rtus_solve_kernel<false, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
-    } else {
-        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, false>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
-        else hipLaunchKernelGGL((rtus_solve_kernel<false, false>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
-    }
+#define RTUS_SOLVE_LAUNCH(F, M) hipLaunchKernelGGL((rtus_solve_kernel<F, M>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q)
+    if (masks) { if (fast) RTUS_SOLVE_LAUNCH(true, true); else RTUS_SOLVE_LAUNCH(false, true); }
+    else { if (fast) RTUS_SOLVE_LAUNCH(true, false); else RTUS_SOLVE_LAUNCH(false, false); }
+#undef RTUS_SOLVE_LAUNCH
     return hipGetLastError();
 }

@@ -252,6 +252,8 @@ struct RayOut { double xq, zq, xi, zi, x_in; };
 template <bool FAST>
 __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, RayOut& out)
 {
+    const TreeNode* __restrict__ tree = a.tree;
+    const double2* __restrict__ curve = a.curve;
     const LensK& k = a.k;
     const int n = a.n;
     const double2 P = in.P;
@@ -330,14 +332,14 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // --- first sign change of d_j along the polyline (main_rt.py:78-99) -----------------------
     const bool fin = isfinite(m) && isfinite(b);   // non-finite line -> the reference ends in (None, None)
     // polyline extent (for the rounding part of the margin): kept in the first record of the tree
-    const double xabs = a.tree[a.n_tree].xc, zabs = a.tree[a.n_tree].xh;
+    const double xabs = tree[a.n_tree].xc, zabs = tree[a.n_tree].xh;
     Walk W;
     // 2e-8 >= the reference's isclose(d, 0) atol, so a skipped box can hold no "point on the line"
     // (main_rt.py:86); the relative part is ~450x the worst fp64 rounding of d_j.
     const double marg0 = 2e-8 + 1e-13 * (fma(fabs(m), xabs, fabs(b)) + zabs);
     lanemask c0pos, c0neg;                          // class of polyline point 0 per ray (neither bit: d_0 == 0)
     {
-        const double2 c0 = a.curve[0];
+        const double2 c0 = curve[0];
         const double t0 = fma(m, c0.x, b);
         c0pos = __ballot(c0.y > t0); c0neg = __ballot(c0.y < t0);       // np.sign(d_0)
     }
@@ -355,9 +357,9 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     for (int pass = 0; pass < 4096; ++pass) {       // > 1 pass only if a parked leaf turned out to hold no change
         const lanemask active0 = W.active;
 #ifdef RTUS_WALK_CXX   // the same pass from the C++ template (for comparison builds)
-        if (pass == 0) walk_pass<false>(W, a.tree, a.n_tree); else walk_pass<true>(W, a.tree, a.n_tree);
+        if (pass == 0) walk_pass<false>(W, tree, a.n_tree); else walk_pass<true>(W, tree, a.n_tree);
 #else
-        if (pass == 0) walk_first_pass(W, a.tree, a.n_tree); else walk_pass<true>(W, a.tree, a.n_tree);
+        if (pass == 0) walk_first_pass(W, tree, a.n_tree); else walk_pass<true>(W, tree, a.n_tree);
 #endif
         // Rays still active walked off the end: no class change anywhere, idx stays -1.  Every ray that left the walk
         // did so at a box whose first 8 points hold its answer.
@@ -368,7 +370,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         // Per-lane leaf: 8 polyline points (the array is padded to a multiple of 8 with copies of the last
         // point: a copy never changes class, so the padding cannot produce a hit).
         const bool mine = lane_bit(left);
-        const double2* __restrict__ cp = a.curve + W.slot;
+        const double2* __restrict__ cp = curve + W.slot;
         double2 c[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) c[i] = cp[i];                        // 8 gathers in flight together
@@ -422,7 +424,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
                     DBG(7);
                     const int j1 = min(U * 8 + 8, n);
                     for (int j = U * 8; j < j1; ++j) {
-                        const double2 c = a.curve[j];
+                        const double2 c = curve[j];
                         const double dj = c.y - (m * c.x + b);        // :78-79, NumPy rounding
                         const lanemask hit = __ballot(fabs(dj) <= 1e-8) & ~on_found;   // :86 isclose(diffs, 0)
                         on_found |= hit;
@@ -431,10 +433,10 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
                 }
             }
         }
-        if (fin && idx < 0 && on >= 0) { const double2 c = a.curve[on]; xi = c.x; zi = c.y; }   // :88-90
+        if (fin && idx < 0 && on >= 0) { const double2 c = curve[on]; xi = c.x; zi = c.y; }   // :88-90
     }
     if (idx >= 0) {                                                    // main_rt.py:106-168
-        const double2 c1p = a.curve[idx], c2p = a.curve[idx + 1];
+        const double2 c1p = curve[idx], c2p = curve[idx + 1];
         const double x1 = c1p.x, y1 = c1p.y, x2 = c2p.x, y2 = c2p.y;
         if (np_isclose(x1, x2, 1e-5, 1e-8)) {                          // :110-123 vertical segment
             const double y = m * x1 + b;

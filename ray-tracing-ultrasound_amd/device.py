@@ -41,7 +41,8 @@ class ShootPlan:
         self.lens = self.p.lens()
         self.flags = 1 if fast else 0
 
-    def run(self, geoms, x_a, z_a, alpha, z_f):
+    def run(self, geoms, x_a, z_a, alpha, z_f, polyline_ready=False):
+        """polyline_ready: the previous ``run`` of this plan used the same ``alpha`` (RTUS_POLYLINE_READY)."""
         _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(z_f, "z_f")
         if geoms.shape != (self.G, 2) or x_a.numel() != self.T or z_a.numel() != self.T \
                 or alpha.numel() != self.N or z_f.numel() != self.N:
@@ -50,7 +51,7 @@ class ShootPlan:
         st = _lib.lib().rtus_shoot_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha),
                                        _p(z_f), self.N, _p(o.get("out8")), _p(o.get("tof4")), _p(o.get("tof")),
                                        _p(o.get("land_x")), _p(o.get("status")), _p(self.ws), self.ws_bytes,
-                                       self.flags, _stream())
+                                       self.flags | (8 if polyline_ready else 0), _stream())
         _lib.check(st, "rtus_shoot_dev")
         return o
 
@@ -75,7 +76,9 @@ class SolvePlan:
         self.lens = self.p.lens()
         self.flags = (1 if fast else 0) | (2 if true_tangent else 0) | (4 if analytic_lens else 0)
 
-    def run(self, geoms, x_a, z_a, alpha, x_rx, z_land=None):
+    def run(self, geoms, x_a, z_a, alpha, x_rx, z_land=None, polyline_ready=False):
+        """polyline_ready: the previous ``run`` of this plan used the same ``alpha`` tensor contents (RTUS_POLYLINE_READY: the
+        lens polyline in the workspace is kept instead of rebuilt)."""
         _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(x_rx, "x_rx")
         if geoms.shape != (self.G, 2) or x_a.numel() != self.T or z_a.numel() != self.T \
                 or alpha.numel() != self.N or x_rx.numel() != self.E:
@@ -84,7 +87,7 @@ class SolvePlan:
         st = _lib.lib().rtus_solve_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha), self.N,
                                        _p(x_rx), self.E, float(self.p.d if z_land is None else z_land), _p(o["tt"]),
                                        _p(o["alpha_root"]), _p(o.get("tt_all")), _p(o.get("alpha_all")), _p(o.get("n_roots")),
-                                       _p(self.ws), self.ws_bytes, self.flags, _stream())
+                                       _p(self.ws), self.ws_bytes, self.flags | (8 if polyline_ready else 0), _stream())
         _lib.check(st, "rtus_solve_dev")
         return o
 

@@ -40,5 +40,20 @@ for fast in (False, True):
         msg = e0.elapsed_time(e1) / K
         nr = o["n_roots"].cpu().numpy()
         el = G * T * 65
+        # the same with the polyline kept between passes (RTUS_POLYLINE_READY)
+        g2 = torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g2, stream=side):
+                for _ in range(K):
+                    plan.run(*a, polyline_ready=True)
+        torch.cuda.current_stream().wait_stream(side)
+        g2.replay(); torch.cuda.synchronize()
+        e0.record(); g2.replay(); e1.record(); torch.cuda.synchronize()
+        msr = e0.elapsed_time(e1) / K
+        o2 = {k: v.clone() for k, v in plan.out.items()}
+        plan.run(*a); torch.cuda.synchronize()
+        same = all(torch.equal(o2[k].view(torch.uint8), plan.out[k].view(torch.uint8)) for k in o2)
+        print(f"{name:6s} fast={int(fast)}: polyline kept {msr*1e3:8.1f} us/pass -> {el/msr/1e3:8.1f} M/s, same bits {same}")
         print(f"{name:6s} fast={int(fast)}: eager {ms*1e3:8.1f} us/pass  graph {msg*1e3:8.1f} us/pass  -> {el/msg/1e3:8.1f} M element-solves/s "
               f"(elements {el}, with root {(nr>0).sum()}, brackets>=1.. roots total {int(nr.sum())})", flush=True)
