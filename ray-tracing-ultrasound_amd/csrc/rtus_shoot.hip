@@ -217,26 +217,22 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         double wlo = pv ? plo : INFINITY, whi = pv ? phi : -INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { wlo = fmin(wlo, __shfl_xor(wlo, o)); whi = fmax(whi, __shfl_xor(whi, o)); }
-        // elements inside the wave's landing interval (ascending aperture: two binary searches; any other order: all of them)
-        int E0 = 0, E1 = a.n_rx;
-        if (rx_sorted) {
-            int lo_i = 0, hi_i = a.n_rx;
-            while (lo_i < hi_i) { const int m = (lo_i + hi_i) >> 1; if (__builtin_amdgcn_readfirstlane((int)(sx[m] < wlo))) lo_i = m + 1; else hi_i = m; }
-            E0 = lo_i;
-            hi_i = a.n_rx;
-            while (lo_i < hi_i) { const int m = (lo_i + hi_i) >> 1; if (__builtin_amdgcn_readfirstlane((int)(sx[m] <= whi))) lo_i = m + 1; else hi_i = m; }
-            E1 = lo_i;
-        }
         const int B = r_raw >> 6, nb = (n + 63) >> 6;
         if (B < nb) {                                                   // (waves past the end of the row trace clones of the last ray)
             unsigned long long* __restrict__ mrow = a.pair_mask + (row * nb + B) * (size_t)a.rx_pad;
+            // 64 elements at a time, one per lane.  Ascending aperture: the elements inside the wave's landing interval are
+            // [#{x < lo}, #{x <= hi}) — two ballot counts per chunk; any other order: all of them.  An element's mask is a
+            // ballot over the pairs (its x by v_readlane: no memory access inside the loop) and lands in the element's lane.
             for (int c0 = 0; c0 < a.rx_pad; c0 += 64) {
+                const bool ev = c0 + lane < a.n_rx;
+                const double xv = sx[min(c0 + lane, a.n_rx - 1)];
+                const int nlo = __popcll(__ballot(ev && xv < wlo)), nhi = __popcll(__ballot(ev && xv <= whi));
+                const int e0 = rx_sorted ? nlo : 0, e1 = rx_sorted ? nhi : min(64, a.n_rx - c0);
                 unsigned long long mine = 0;
-                const int e1 = min(E1, c0 + 64);
-                for (int e = max(E0, c0); e < e1; ++e) {
-                    const double x = sx[e];
+                for (int e = e0; e < e1; ++e) {
+                    const double x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), e), __builtin_amdgcn_readlane(__double2loint(xv), e));
                     const lanemask m = __ballot(plo <= x && x <= phi && x != l0);
-                    mine = lane == (e & 63) ? m : mine;
+                    mine = lane == e ? m : mine;
                 }
                 mrow[c0 + lane] = mine;
             }

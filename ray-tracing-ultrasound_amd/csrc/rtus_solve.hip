@@ -64,7 +64,7 @@ struct SolveArgs {
     const double* __restrict__ x_rx;    // [n_rx]
     double z_land;
     int n_rx, chunks;                   // chunks = ceil(n_rx / 64)
-    long long n_tasks;                  // rows * chunks
+    long long n_tasks;                  // mask mode: rows * n_rx (flat element lanes); scan mode: rows * chunks (wave-tasks)
     double* __restrict__ tt;            // [rows][n_rx] least-time root (NaN: none)
     double* __restrict__ alpha_root;    // nullable, its launch angle
     double* __restrict__ tt_all;        // nullable [rows][n_rx][RTUS_MAX_ROOTS]
@@ -102,13 +102,27 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
 
     STAMP(0);
     // ---- A: brackets -----------------------------------------------------------------------------------------------
-    const long long task = (long long)blockIdx.x * RTUS_SOLVE_WAVES + wv;
-    const bool task_live = task < q.n_tasks;                           // wave-uniform
-    const long long t_row = task_live ? task / q.chunks : 0;
-    const int chunk = task_live ? (int)(task - t_row * q.chunks) : 0;
-    const int e_raw = chunk * 64 + lane;
-    const bool live = task_live && e_raw < q.n_rx;
-    const int e = min(e_raw, q.n_rx - 1);
+    // MASKS: lanes = (row, element) pairs, flat — a 65-element aperture fills its waves (64 lanes of one row + 1 lane in a wave
+    // of its own would run every phase for that one lane); scan mode: wave-task = (row, 64-element chunk), the row wave-uniform.
+    long long t_row;
+    int e;
+    bool live, task_live;
+    if (MASKS) {
+        const long long flat = (long long)blockIdx.x * RTUS_SOLVE_TPB + threadIdx.x;
+        live = flat < q.n_tasks;                                       // n_tasks = rows * n_rx here
+        const long long fl = live ? flat : q.n_tasks - 1;
+        t_row = fl / q.n_rx;
+        e = (int)(fl - t_row * q.n_rx);
+        task_live = __any(live);
+    } else {
+        const long long task = (long long)blockIdx.x * RTUS_SOLVE_WAVES + wv;
+        task_live = task < q.n_tasks;                                  // wave-uniform; n_tasks = rows * chunks here
+        t_row = task_live ? task / q.chunks : 0;
+        const int chunk = task_live ? (int)(task - t_row * q.chunks) : 0;
+        const int e_raw = chunk * 64 + lane;
+        live = task_live && e_raw < q.n_rx;
+        e = min(e_raw, q.n_rx - 1);
+    }
     const double xe = q.x_rx[e];
     int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
     auto add_bracket = [&](bool yes, int r) {
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         }
     };
     if (MASKS && task_live) {
-        const double* __restrict__ lrow = q.land_x + (size_t)t_row * n;
-        const unsigned long long* __restrict__ mrow = q.pair_mask + (size_t)t_row * q.nb * q.rx_pad + e_raw;   // e_raw < rx_pad
+        const double* __restrict__ lrow = q.land_x + (size_t)t_row * n;                                  // per lane: a wave may span rows
+        const unsigned long long* __restrict__ mrow = q.pair_mask + (size_t)t_row * q.nb * q.rx_pad + e;
         for (int B0 = 0; B0 < q.nb; B0 += 8) {                          // eight blocks per trip: their loads are in flight together
             unsigned long long m[8];
             double la[8], lb[8];
@@ -214,10 +228,18 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         const int ii = min(i0 + lane, total - 1);                       // idle lanes redo the last bracket (no store)
         const unsigned slot = items[ii];
         const int br = item_r[ii];
-        const int sw = (int)(slot >> 8), sl = (int)((slot >> 2) & 63);  // (RTUS_MAX_ROOTS = 4: slot = ((wave * 64) + lane) * 4 + k)
-        const long long itask = (long long)blockIdx.x * RTUS_SOLVE_WAVES + sw;
-        const long long row = itask / q.chunks;
-        const int ie = (int)(itask - row * q.chunks) * 64 + sl;
+        const int owner = (int)(slot >> 2);                             // the thread that found the bracket (RTUS_MAX_ROOTS = 4)
+        long long row;
+        int ie;
+        if (MASKS) {
+            const long long fl = (long long)blockIdx.x * RTUS_SOLVE_TPB + owner;
+            row = fl / q.n_rx;
+            ie = (int)(fl - row * q.n_rx);
+        } else {
+            const long long itask = (long long)blockIdx.x * RTUS_SOLVE_WAVES + (owner >> 6);
+            row = itask / q.chunks;
+            ie = (int)(itask - row * q.chunks) * 64 + (owner & 63);
+        }
         const int g = (int)(row / a.n_tx), tx = (int)(row - (long long)g * a.n_tx);
         const double xr = q.x_rx[ie];
         const double* __restrict__ lrow = q.land_x + (size_t)row * n;
@@ -375,9 +397,9 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     a.flags = flags;
     q.alpha = alpha; q.land_x = land; q.land_box = boxes; q.pair_mask = pmask; q.rx_pad = (n_rx + 63) & ~63; q.nb = (n + 63) / 64; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;
     q.chunks = (n_rx + 63) / 64;
-    q.n_tasks = (long long)n_geom * n_tx * q.chunks;
+    q.n_tasks = masks ? (long long)n_geom * n_tx * n_rx : (long long)n_geom * n_tx * q.chunks;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
-    const long long blocks = (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
+    const long long blocks = masks ? (q.n_tasks + RTUS_SOLVE_TPB - 1) / RTUS_SOLVE_TPB : (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks);
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
