@@ -169,20 +169,10 @@ __global__ __launch_bounds__(RTUS_GEOM1_TPB) void rtus_geom1_kernel(LensK k, con
 // and ~100 dependent scalar loads of latency.  Asked per PAIR it is three compares against the few elements the wave's
 // landing interval covers, right where the landing points are still in registers: a ballot per covered element is the
 // 64-bit mask of the pairs that bracket it, and the element's lane of the solve kernel later reads one mask per 64-ray block.
+// Counters, 16,384 rows x 905 rays: 1,340 VALU + 553 scalar instructions per wave against 1,200 + 440 without the emission.
 template <bool FAST, bool EMIT>
 __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS_SHOOT_MIN_WAVES, 8))) void rtus_shoot_kernel(ShootArgs a)
 {
-    __shared__ double sx[EMIT ? RTUS_SOLVE_MASK_MAX_RX : 1];
-    bool rx_sorted = true;
-    if (EMIT) {                                    // the aperture, once per workgroup; is it ascending?
-        bool asc = true;
-        for (int i = threadIdx.x; i < a.n_rx; i += RTUS_BLOCK) {
-            const double v = a.x_rx[i];
-            sx[i] = v;
-            asc = asc && (i == 0 || a.x_rx[i - 1] <= v);
-        }
-        rx_sorted = __syncthreads_and(asc) != 0;
-    }
     const int n = a.n;
     const int r_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = r_raw < n;
@@ -220,14 +210,17 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         const int B = r_raw >> 6, nb = (n + 63) >> 6;
         if (B < nb) {                                                   // (waves past the end of the row trace clones of the last ray)
             unsigned long long* __restrict__ mrow = a.pair_mask + (row * nb + B) * (size_t)a.rx_pad;
-            // 64 elements at a time, one per lane.  Ascending aperture: the elements inside the wave's landing interval are
-            // [#{x < lo}, #{x <= hi}) — two ballot counts per chunk; any other order: all of them.  An element's mask is a
-            // ballot over the pairs (its x by v_readlane: no memory access inside the loop) and lands in the element's lane.
+            // 64 elements at a time, one per lane (a coalesced load per wave: no LDS copy, no workgroup barrier in front of the
+            // trace).  A chunk in ascending order: its elements inside the wave's landing interval are [#{x < lo}, #{x <= hi}) —
+            // two ballot counts; any other order: all of them.  An element's mask is a ballot over the pairs (its x by
+            // v_readlane: no memory access inside the loop) and lands in the element's lane.
             for (int c0 = 0; c0 < a.rx_pad; c0 += 64) {
                 const bool ev = c0 + lane < a.n_rx;
-                const double xv = sx[min(c0 + lane, a.n_rx - 1)];
+                const double xv = a.x_rx[min(c0 + lane, a.n_rx - 1)];
+                const double xn = __shfl_down(xv, 1);
+                const bool asc = !__ballot(ev && lane < 63 && c0 + lane + 1 < a.n_rx && !(xv <= xn));
                 const int nlo = __popcll(__ballot(ev && xv < wlo)), nhi = __popcll(__ballot(ev && xv <= whi));
-                const int e0 = rx_sorted ? nlo : 0, e1 = rx_sorted ? nhi : min(64, a.n_rx - c0);
+                const int e0 = asc ? nlo : 0, e1 = asc ? nhi : min(64, a.n_rx - c0);
                 unsigned long long mine = 0;
                 for (int e = e0; e < e1; ++e) {
                     const double x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), e), __builtin_amdgcn_readlane(__double2loint(xv), e));
