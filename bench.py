@@ -243,8 +243,8 @@ class Timed:
 
 
 def load_profile_json(name):
-    """profiles/<name>: the newest round's file wins (r02 over r01)."""
-    for tag in ("r02", "r01"):
+    """profiles/<name>: the newest round's file wins (r03 over r02 over r01)."""
+    for tag in ("r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", name.format(tag=tag))
         if os.path.exists(p):
             try:
@@ -773,7 +773,9 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
     del outf, planf, timed
     # --- consumers of a travel-time table: the memory-bound kernels of the library ------------------
     res.update(consumer_measurements(dev_api, t64, torch, dev))
-    # --- root-finding pulse-echo solve: the reference sweep's 210 geometries x 65 elements --------------------------
+    # --- root-finding pulse-echo solve (the north-star's replacement for the grid scan), device-resident ----------------
+    res.update(solve_measurements(dev_api, rtus, t64, torch))
+    # ... and once through the host-buffer API
     R = ref_inputs("ref_sweep")
     sol = [None]
 
@@ -782,11 +784,78 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
 
     dtm = _best_ms(torch, one_solve, 3, blocks=3) * 1e-3
     tt = sol[0]
-    res["solve_sweep_host_api"] = {"ms_per_pass": round(dtm * 1e3, 3), "elements": int(tt.size),
+    res["solve_sweep_host_api"] = {"ms_per_pass": round(dtm * 1e3, 3), "elements": int(tt.size), "M_element_solves_per_s": round(tt.size / dtm / 1e6, 1),
                                    "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe"}
     # --- the reference's calling pattern: 210 sequential shoot_rays(N = 905) calls + matcher (main_rt.py:464-504) ------
     res["sweep_like_main_rt"] = sweep_like_reference(rtus)
     return res
+
+
+def solve_inputs(kind):
+    """solve_sweep: the reference's own sweep (main_rt.py:464-482: 210 geometries, tx = the centre element, 65 rx, N = 905);
+    solve_scale: the reference geometry scaled up — 16 pipe geometries x 1024 tx x 65 rx over the same N = 905 grid."""
+    import rtus
+    d = rtus.Params().d
+    n = 905
+    if kind == "solve_sweep":
+        geoms = np.array([[r * 1e-2, o * 1e-3] for r in range(1, 11) for o in range(-10, 11)])
+        xa = np.array([0.0])
+    else:
+        geoms = np.array([[0.02 + 0.005 * i, 0.0004 * (i - 7.5)] for i in range(16)])
+        xa = (np.arange(1024) - 511.5) * 0.3e-4
+    return dict(n=n, geoms=geoms, xa=xa, za=np.full(xa.size, d), alpha=np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n),
+                x_rx=rtus.reference_elements())
+
+
+def solve_measurements(dev_api, rtus, t64, torch):
+    """rtus_solve_dev, inputs and outputs resident in HBM, K passes replayed as one hipGraph.  A pass = polyline + box
+    records, grid trace (905 rays per (geometry, tx) row, with the bracket masks), bracket refinement: every element of every
+    row gets its travel time(s).  `roofline` prices the pass against HBM as the contract asks (16 B written per element:
+    travel time + launch angle); `roofline_valu` carries what binds it (SQ counters of the two kernels from profiles/)."""
+    out = {}
+    valu_doc, valu_src = load_profile_json("valu_{tag}.json")
+    for kind, K in (("solve_sweep", 200), ("solve_scale", 10)):
+        S = solve_inputs(kind)
+        G, T, E, N = S["geoms"].shape[0], S["xa"].size, S["x_rx"].size, S["n"]
+        a = [t64(S[k]) for k in ("geoms", "xa", "za", "alpha", "x_rx")]
+        entry = {"elements_per_pass": G * T * E, "grid_rays_per_pass": G * T * N}
+        for fast in (False, True):
+            plan = dev_api.SolvePlan(G, T, N, E, params=rtus.Params(), fast=fast)
+            for _ in range(3):
+                o = plan.run(*a)
+            torch.cuda.synchronize()
+            nroot = int(torch.isfinite(o["tt"]).sum().item())
+            timed = Timed(torch, lambda s: plan.run(*a), K)
+            dt, ms = timed.run(lambda: None)
+            timed_keep = Timed(torch, lambda s: plan.run(*a, polyline_ready=True), K)
+            dtk, msk = timed_keep.run(lambda: None)
+            el = G * T * E
+            algb = el * 16 + (2 * G + 2 * T + N + E) * 8
+            e2 = {"us_per_pass": round(ms * 1e3, 2), "M_element_solves_per_s": round(el / ms / 1e3, 1),
+                  "us_per_pass_polyline_kept": round(msk * 1e3, 2), "M_element_solves_per_s_polyline_kept": round(el / msk / 1e3, 1),
+                  "elements_with_a_ray_path": nroot,
+                  "roofline": {"bound": "hbm", "binds": "launch floor + the fp64 dependent chain of a traced ray (few waves per SIMD)" if kind == "solve_sweep"
+                               else "valu_issue (grid trace 2/3, refinement 1/3)", "kernel": "rtus_shoot_kernel<%s, true> + rtus_solve_kernel<%s, true>" % (("true",) * 2 if fast else ("false",) * 2),
+                               "algorithmic_bytes_per_pass": algb, "achieved": round(algb / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(algb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
+            key = kind + ("_fastmath" if fast else "")
+            if valu_doc and key in valu_doc:
+                v = dict(valu_doc[key])
+                v["source"] = valu_src + " (rocprofv3 --pmc SQ_* passes of scripts/run_solve_once.py; not collected in this run)"
+                if v.get("issue_cycles_per_pass") and v.get("clock_ghz"):
+                    t_issue = v["issue_cycles_per_pass"] / 1024.0 / (v["clock_ghz"] * 1e9)
+                    v["issue_bound_us"] = round(t_issue * 1e6, 2)
+                    v["frac_of_issue_bound"] = round(t_issue * 1e3 / ms, 4)
+                if v.get("fp64_flop_per_pass"):
+                    v["fp64_TFLOP_per_s"] = round(v["fp64_flop_per_pass"] / (ms * 1e-3) / 1e12, 2)
+                    v["frac_of_fp64_vector_peak"] = round(v["fp64_flop_per_pass"] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4)
+                e2["roofline_valu"] = v
+            entry["vector_form" if fast else "reference_arithmetic"] = e2
+            del plan, timed, timed_keep
+        entry["note"] = ("polyline_kept: RTUS_POLYLINE_READY — the lens polyline of the alpha grid stays in the workspace between passes "
+                         "(main_rt.py recomputes the same x_p, z_p for each of its 210 geometries)")
+        out[kind] = entry
+    return out
 
 
 def consumer_measurements(dev_api, t64, torch, dev):

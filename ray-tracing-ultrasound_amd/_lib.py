@@ -52,12 +52,20 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ray-tracing-ultrasound_amd/csrc`. There is no CPU fallback.")
-    # The NumPy call surface (api.py, drivers.py) needs no PyTorch and does not import it.  Only device.py / dist.py do
-    # (device memory, streams, torch.distributed), at THEIR import — before the library is loaded through them, so that
-    # PyTorch's bundled libamdhip64.so.7 is the one HIP runtime of the process.  RTUS_PRELOAD_TORCH=1 forces that order
-    # for a process that starts with the NumPy API and moves to torch tensors later.
-    if os.environ.get("RTUS_PRELOAD_TORCH", "0") == "1" and "torch" not in sys.modules:
-        import torch  # noqa: F401
+    # ONE HIP runtime per process.  The NumPy call surface (api.py, drivers.py) needs no PyTorch and does not import it; but a
+    # process may import torch LATER (device.py / dist.py do), and PyTorch's wheel carries its own libamdhip64.so (SONAME
+    # libamdhip64.so.7, found by libtorch_hip through RPATH=$ORIGIN under the NAME libamdhip64.so — which glibc does not match
+    # against an already loaded /opt/rocm copy).  Two runtimes in one process would hand torch's device pointers and streams to a
+    # library bound to the other one.  So when torch is installed its copy of the runtime is loaded first — a dlopen, not an
+    # import: librtus.so's NEEDED libamdhip64.so.7 then resolves to it by SONAME, and a later `import torch` finds the same file
+    # already mapped.  Without torch the system runtime (/opt/rocm/lib) is used.  RTUS_SYSTEM_HIP=1 skips this.
+    if "torch" not in sys.modules and os.environ.get("RTUS_SYSTEM_HIP", "0") != "1":
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
     L.rtus_strerror.argtypes = [ip]

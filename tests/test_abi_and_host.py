@@ -3,6 +3,7 @@ argument validation mirrors the reference's error behaviour.  No compute calls (
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -110,3 +111,21 @@ def test_header_is_plain_c():
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
                         os.path.join(ROOT, "include", "rtus.h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """NumPy API first (loads librtus.so), torch afterwards: the process must still hold ONE libamdhip64 (two
+    runtimes in one process hand torch's pointers to a library bound to the other).  Needs no GPU: only the loader runs."""
+    import subprocess
+    code = r"""
+import sys, os
+sys.path.insert(0, %r)
+import rtus
+rtus.lib()
+import torch
+paths = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})
+print(len(paths), paths)
+assert len(paths) == 1, paths
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
