@@ -113,8 +113,12 @@ def planar_inputs(cfg, rank, world):
                 rows_total=n_all, lo=rank * n_e)
 
 
-def _strong_rows(n_rows, rank, world):
-    per = -(-n_rows // world)
+def _strong_rows(n_rows, rank, world, n_f, elem_bytes):
+    """rows [lo, hi) of rank `rank`: equal shards rounded up to the table kernels' rows per workgroup, so that every shard
+    starts on a block boundary of the whole table and the sharded table is bit for bit the one-GPU table (rtus_shard_rows)"""
+    import rtus
+    per = int(rtus.lib().rtus_shard_rows(n_rows, n_f, elem_bytes, world))
+    assert per > 0
     lo = min(rank * per, n_rows)
     return lo, min(lo + per, n_rows), per
 
@@ -128,7 +132,7 @@ def lens_inputs(rank, world, n_rows=1024):
     if SMALL:
         n_rows, g = min(n_rows, 64), 128
     x_all = (np.arange(n_rows) - (n_rows - 1) / 2.0) * 0.3e-4
-    lo, hi, per = _strong_rows(n_rows, rank, world)
+    lo, hi, per = _strong_rows(n_rows, rank, world, g * g, 4)
     xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, g), np.linspace(0.03, 0.07, g))
     return dict(xe=x_all[lo:hi], ze=np.full(hi - lo, rtus.Params().d), xf=xs.ravel(), zf=zs.ravel(),
                 n_e=hi - lo, n_f=xs.size, rows_total=n_rows, lo=lo)
@@ -144,7 +148,7 @@ def fmc_inputs(rank, world, n_tx=2048):
         n_tx = min(n_tx, 64)
     x_tx = (np.arange(n_tx) - (n_tx - 1) / 2.0) * 0.3e-3
     x_rx = (np.arange(2048) - 1023.5) * 0.3e-3
-    lo, hi, per = _strong_rows(n_tx, rank, world)
+    lo, hi, per = _strong_rows(n_tx, rank, world, 2048, 8)
     return dict(z_if=z_m, c=c_m, xe=x_tx[lo:hi], ze=np.zeros(hi - lo), xf=x_rx, zf=np.full(2048, 2.0 * z_r),
                 n_e=hi - lo, n_f=2048, rows_total=n_tx, lo=lo)
 
@@ -315,7 +319,8 @@ def main(argv=None):
         f32 = wl == "cfg4_lens_f32"
         tdt = torch.float32 if f32 else torch.float64
         slots = 2 if gather_step else (max(1, args.streams) if wl in PLANAR else 1)
-        m = dist_api.RowShardedMatrix(W["rows_total"], n_f, dtype=tdt, device=dev, slots=slots)
+        align = dev_api.rows_per_block(W["rows_total"], n_f, tdt) if scaling == "strong" else 1
+        m = dist_api.RowShardedMatrix(W["rows_total"], n_f, dtype=tdt, device=dev, slots=slots, align=align)
         if m.per < n_e or (scaling == "strong" and (m.lo, m.hi) != (W["lo"], W["lo"] + n_e)):
             raise SystemExit("row sharding of the inputs and of the matrix disagree")
         units_per_step = n_e * n_f                       # this rank's solves per step
@@ -327,12 +332,12 @@ def main(argv=None):
             t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
             xe, ze, xf, zf = t32(W["xe"]), t32(W["ze"]), t32(W["xf"]), t32(W["zf"])
             lens = rtus.Params().lens()
-            fn = rtus.lib().rtus_tt_lens_f32_dev
+            fn = rtus.lib().rtus_tt_lens_f32_rows_dev        # rows [lo, lo + n_e) of the rows_total-row table: the one-GPU table's bits
             kernel = "rtus_tt_lens_kernel<float, true, false>"
 
             def launch(b):
-                st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, xf.data_ptr(),
-                        zf.data_ptr(), n_f, m.local(b).data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                st = fn(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, xe.data_ptr(), ze.data_ptr(), n_e, W["lo"], W["rows_total"],
+                        xf.data_ptr(), zf.data_ptr(), n_f, m.local(b).data_ptr(), None, torch.cuda.current_stream().cuda_stream)
                 assert st == 0
         else:
             xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
@@ -508,8 +513,9 @@ def fmc_strong(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_ove
     """BASELINE configs[4] on N GPUs: the 2048 x 2048 FMC table, tx rows sharded, collective-free solve + ONE all-gather."""
     W = fmc_inputs(rank, world)
     n_e, n_f = W["n_e"], W["n_f"]
-    m = dist_api.RowShardedMatrix(W["rows_total"], n_f, device=dev, slots=1)
-    plan = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=m.local(0)[:n_e])
+    m = dist_api.RowShardedMatrix(W["rows_total"], n_f, device=dev, slots=1, align=dev_api.rows_per_block(W["rows_total"], n_f))
+    plan = dev_api.LayersPlan(W["z_if"], W["c"], t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"]), out=m.local(0)[:n_e],
+                              row0=W["lo"], n_rows_total=W["rows_total"])
     for _ in range(5):
         plan.run()
     res = {"workload": DESCR["cfg5_fmc"], "rows_per_gpu": n_e}

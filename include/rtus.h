@@ -77,6 +77,7 @@ int rtus_release(int device);
  * polyline form a tree (forward skip links that land where each box ends, leaves covering the polyline in order).
  * counts[0] = division mismatches, [1] = square-root mismatches, [2] = structure violations, [3] = n_math.  All zero
  * on a healthy build. */
+/* Runs on `device` (validated; the caller's current device is restored) on the staging arena's own stream. */
 int rtus_selftest(const rtus_lens *lens, int n_rays, long long n_math, unsigned long long *counts, int device);
 
 /* ------------------------------------------------------------------------------------------
@@ -260,6 +261,55 @@ int rtus_tt_lens_f32(const rtus_lens *lens, double alpha_lo, double alpha_hi,
                      const float *xe, const float *ze, int n_e,
                      const float *xf, const float *zf, int n_f,
                      float *tt, float *alpha_out, int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Row shards of a travel-time table, and one call spread over several GPUs (SURVEY 8(b) "rtus_allgather(...)/multi-GPU
+ * variant", 8(e)).  NOT IN THE REFERENCE (it has no device or process boundary at all).
+ *
+ * The table kernels solve `rows_per_block` consecutive elements per workgroup and start each solve from its predecessors
+ * in the block.  rows_per_block is a function of the WHOLE table (rtus_table_rows_per_block), and the *_rows_dev entry
+ * points keep workgroups aligned to the whole table's blocks: a shard [row0, row0 + n_rows) whose row0 is a multiple of
+ * rows_per_block gets, bit for bit, the rows the one-launch table has (an unaligned shard is still correct to the solver's
+ * accuracy; its first partial block has fewer predecessors).  rtus_shard_rows = rows per shard for n_shards equal shards,
+ * rounded up to that multiple.
+ *
+ * rtus_*_multi: host buffers in, host table out, the rows spread over `devices[0 .. n_dev)` (a device may be listed more
+ * than once: one arena and stream per entry); every device copies its block straight into the caller's rows — a host
+ * result needs no exchange between the GPUs.
+ * rtus_*_multi_dev: device i holds its own copies of the inputs (d_xe[i], d_ze[i]: ALL n_e elements; d_xf[i], d_zf[i]) and
+ * of the padded table d_tt[i] [n_dev * rtus_shard_rows(...)][n_f]; it solves its row block in place on streams[i].
+ * gather = 0 leaves the table sharded; gather = 1 reassembles it on every device by an in-place ncclAllGather over
+ * single-process communicators (ncclCommInitAll; RCCL over xGMI, bound with dlopen at the first such call —
+ * RTUS_ERR_UNSUPPORTED when librccl cannot be loaded or the communicators cannot be made).  Asynchronous.
+ * ---------------------------------------------------------------------------------------- */
+int rtus_table_rows_per_block(long long n_rows_total, int n_f, int elem_bytes);              /* elem_bytes: 8 (fp64) or 4 (fp32) */
+long long rtus_shard_rows(long long n_rows_total, int n_f, int elem_bytes, int n_shards);
+
+int rtus_tt_layers_rows_dev(const double *z_if, const double *c, int n_if,
+                            const double *d_xe, const double *d_ze, int n_rows, long long row0, long long n_rows_total,
+                            const double *d_xf, const double *d_zf, int n_f, double *d_tt, void *stream);
+int rtus_tt_lens_rows_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                          const double *d_xe, const double *d_ze, int n_rows, long long row0, long long n_rows_total,
+                          const double *d_xf, const double *d_zf, int n_f, double *d_tt, double *d_alpha_out, void *stream);
+int rtus_tt_lens_f32_rows_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                              const float *d_xe, const float *d_ze, int n_rows, long long row0, long long n_rows_total,
+                              const float *d_xf, const float *d_zf, int n_f, float *d_tt, float *d_alpha_out, void *stream);
+
+int rtus_tt_layers_multi(const double *z_if, const double *c, int n_if,
+                         const double *xe, const double *ze, int n_e, const double *xf, const double *zf, int n_f,
+                         double *tt, const int *devices, int n_dev);
+int rtus_tt_lens_f32_multi(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                           const float *xe, const float *ze, int n_e, const float *xf, const float *zf, int n_f,
+                           float *tt, const int *devices, int n_dev);
+
+int rtus_tt_layers_multi_dev(const double *z_if, const double *c, int n_if,
+                             const double *const *d_xe, const double *const *d_ze, int n_e,
+                             const double *const *d_xf, const double *const *d_zf, int n_f, double *const *d_tt,
+                             const int *devices, int n_dev, void *const *streams, int gather);
+int rtus_tt_lens_f32_multi_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                               const float *const *d_xe, const float *const *d_ze, int n_e,
+                               const float *const *d_xf, const float *const *d_zf, int n_f, float *const *d_tt,
+                               const int *devices, int n_dev, void *const *streams, int gather);
 
 /* ------------------------------------------------------------------------------------------
  * Consumers of a travel-time table.  NOT IN THE REFERENCE, which stops at the travel times

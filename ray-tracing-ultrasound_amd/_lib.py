@@ -110,6 +110,22 @@ def lib():
     L.rtus_solve.restype = ip
     for name in ("rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32"):
         getattr(L, name).restype = ip
+    ll = C.c_longlong
+    L.rtus_table_rows_per_block.argtypes = [ll, ip, ip]
+    L.rtus_table_rows_per_block.restype = ip
+    L.rtus_shard_rows.argtypes = [ll, ip, ip, ip]
+    L.rtus_shard_rows.restype = ll
+    L.rtus_tt_layers_rows_dev.argtypes = [dp, dp, ip, dp, dp, ip, ll, ll, dp, dp, ip, dp, vp]
+    L.rtus_tt_lens_rows_dev.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, ll, ll, dp, dp, ip, dp, dp, vp]
+    L.rtus_tt_lens_f32_rows_dev.argtypes = L.rtus_tt_lens_rows_dev.argtypes
+    L.rtus_tt_layers_multi.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, C.POINTER(C.c_int), ip]
+    L.rtus_tt_lens_f32_multi.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, dp, dp, ip, dp, C.POINTER(C.c_int), ip]
+    pp = C.POINTER(C.c_void_p)
+    L.rtus_tt_layers_multi_dev.argtypes = [dp, dp, ip, pp, pp, ip, pp, pp, ip, pp, C.POINTER(C.c_int), ip, pp, ip]
+    L.rtus_tt_lens_f32_multi_dev.argtypes = [LP, C.c_double, C.c_double, pp, pp, ip, pp, pp, ip, pp, C.POINTER(C.c_int), ip, pp, ip]
+    for name in ("rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev", "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi",
+                 "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev", "rtus_tt_lens_f32_multi_dev"):
+        getattr(L, name).restype = ip
     for name in ("rtus_shoot_dev", "rtus_shoot", "rtus_match_dev", "rtus_match", "rtus_ray_hits_dev",
                  "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_device_count"):
         getattr(L, name).restype = ip
@@ -127,4 +143,7 @@ EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_
            "rtus_ray_hits_dev", "rtus_ray_hits", "rtus_tt_layers_dev", "rtus_tt_layers", "rtus_tt_layers_batch_dev",
            "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",
            "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve",
-           "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm")
+           "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm",
+           "rtus_table_rows_per_block", "rtus_shard_rows", "rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev",
+           "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi", "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev",
+           "rtus_tt_lens_f32_multi_dev")

@@ -214,10 +214,19 @@ def ray_hits(land_x, x_rx, atol=1e-4, rtol=1e-5, *, device=0):
     return rh.astype(bool).reshape(lead + (N,))
 
 
-def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None, device=0):
+def _device_list(devices):
+    d = np.ascontiguousarray(devices, dtype=np.int32).reshape(-1)
+    if d.size == 0:
+        raise ValueError("devices must list at least one GPU")
+    return d
+
+
+def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None, device=0, devices=None):
     """Element x focal-point Fermat travel times through horizontal layers -> tt[n_e, n_f].
 
     ``out``: optional float64 [n_e, n_f] result buffer, returned as ``tt``.
+    ``devices``: a list of GPU indices — the table's rows are solved in contiguous blocks on all of them at once and each
+    GPU copies its block straight into ``tt`` (rtus_tt_layers_multi); the result is bit for bit the one-GPU table.
 
     NOT in the reference (no planar interfaces there): parity unpinned, see DESIGN.md.
     """
@@ -229,6 +238,14 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None,
     if xe.shape != ze.shape or xf.shape != zf.shape:
         raise ValueError("xe/ze and xf/zf must pair up")
     tt = _out(out, (xe.size, xf.size), np.float64)
+    if devices is not None:
+        if return_iters:
+            raise ValueError("return_iters is a one-device diagnostic")
+        dv = _device_list(devices)
+        st = _lib.lib().rtus_tt_layers_multi(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze), xe.size,
+                                             _ptr(xf), _ptr(zf), xf.size, _ptr(tt), dv.ctypes.data_as(C.POINTER(C.c_int)), dv.size)
+        _lib.check(st, "rtus_tt_layers_multi")
+        return tt
     iters = np.empty((xe.size, xf.size), dtype=np.uint8) if return_iters else None
     st = _lib.lib().rtus_tt_layers(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze),
                                    xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), int(device))
@@ -237,7 +254,7 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None,
 
 
 def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, alpha_hi=None, dtype=np.float64,
-                     return_alpha=False, out=None, device=0):
+                     return_alpha=False, out=None, device=0, devices=None):
     """Element x focal-point Fermat travel times through the reference's curved lens surface
     (h(alpha) of main_rt.py:180-189): elements in the lens (c1), targets in the water (c2) -> tt[n_e, n_f].
 
@@ -258,6 +275,14 @@ def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, al
     tt = _out(out, (xe.size, xf.size), dt)                       # out: optional caller-owned result buffer
     al = np.empty((xe.size, xf.size), dtype=dt) if return_alpha else None
     lens = p.lens()
+    if devices is not None:                      # fp32 table over several GPUs (BASELINE configs[3]): rtus_tt_lens_f32_multi
+        if dt != np.float32 or return_alpha:
+            raise ValueError("devices=[...] is the float32 table without the alpha output")
+        dv = _device_list(devices)
+        st = _lib.lib().rtus_tt_lens_f32_multi(C.byref(lens), a_lo, a_hi, _ptr(xe), _ptr(ze), xe.size, _ptr(xf), _ptr(zf), xf.size,
+                                               _ptr(tt), dv.ctypes.data_as(C.POINTER(C.c_int)), dv.size)
+        _lib.check(st, "rtus_tt_lens_f32_multi")
+        return tt
     fn = _lib.lib().rtus_tt_lens if dt == np.float64 else _lib.lib().rtus_tt_lens_f32
     st = fn(C.byref(lens), a_lo, a_hi, _ptr(xe), _ptr(ze), xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(al),
             int(device))

@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <dlfcn.h>
 #include <mutex>
 #include <string.h>
+#include <thread>
+#include <vector>
 #include "../../include/rtus.h"
 
 // launchers (rtus_shoot.hip / rtus_match.hip / rtus_fermat.hip)
@@ -28,13 +31,17 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
 hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int n_if, const double* xe, const double* ze,
                                        int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
                                        long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s);
+hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                                      int row0, long long n_rows_total, const double* xf, const double* zf, int n_f, double* tt,
+                                      hipStream_t s);
+int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_bytes);
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
-                                   double* alpha_out, hipStream_t s);
+                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s);
 hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi, const float* xe, const float* ze,
                                    int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
-                                   hipStream_t s);
+                                   int row0, long long n_rows_total, hipStream_t s);
 
 hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* delays, hipStream_t s);
 hipError_t rtus_launch_tfm(const float* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* tt_tx,
@@ -57,6 +64,7 @@ static int hip_fail(hipError_t e) { g_last_hip = (int)e; return RTUS_ERR_HIP; }
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kMaxDevices = 64;
+constexpr int kMaxSlots = 4;                        // arenas per device: a multi-device call may list a device more than once
 constexpr size_t kPinBytes = (size_t)1 << 20;       // per direction: calls that move less than this go through ONE copy
 struct Arena {
     std::mutex mu;
@@ -65,7 +73,7 @@ struct Arena {
     char* pin = nullptr;                            // 2 x kPinBytes of page-locked host memory: [0, k) up, [k, 2k) down
     hipStream_t stream = nullptr;
 };
-Arena g_arena[kMaxDevices];
+Arena g_arena[kMaxDevices][kMaxSlots];
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The twins run on `device` and put the caller's current device back when they return.
@@ -83,16 +91,22 @@ struct Session {                       // one host-buffer call on one device
     Xfer up[8], down[8];
     int n_up = 0, n_down = 0;
 
-    int open(int device, size_t dev_bytes)
+    int dev_index = -1;
+    // the session ends with its stream drained whatever happened in between (an early return after flush() must not leave
+    // copies in flight while the next call re-uses the page-locked buffer)
+    ~Session() { if (a && a->stream) (void)hipStreamSynchronize(a->stream); }
+    int open(int device, size_t dev_bytes, int slot = 0)
     {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTUS_ERR_NO_DEVICE;
-        if (device < 0 || device >= n || device >= kMaxDevices) return RTUS_ERR_NO_DEVICE;
+        if (device < 0 || device >= n || device >= kMaxDevices || slot < 0 || slot >= kMaxSlots) return RTUS_ERR_NO_DEVICE;
+        dev_index = device;
         int cur = -1;
         if (hipGetDevice(&cur) == hipSuccess && cur != device) guard.prev = cur;
         HIP_TRY(hipSetDevice(device));
-        a = &g_arena[device];
-        lock = std::unique_lock<std::mutex>(a->mu);
+        Arena* ar = &g_arena[device][slot];
+        lock = std::unique_lock<std::mutex>(ar->mu);
+        a = ar;
         if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         if (!a->pin) HIP_TRY(hipHostMalloc((void**)&a->pin, 2 * kPinBytes, hipHostMallocDefault));
         if (a->cap < dev_bytes) {                                    // grow-only; the previous call has synchronised
@@ -190,7 +204,7 @@ static int lens_host(const rtus_lens* lens, double a_lo, double a_hi, const R* x
     R* dtt = S.take<R>(tot);
     R* dal = alpha_out ? S.take<R>(tot) : nullptr;
     HIP_TRY(S.flush());
-    LAUNCH_TRY(launch(*lens, a_lo, a_hi, dxe, dze, n_e, dxf, dzf, n_f, dtt, dal, S.a->stream));
+    LAUNCH_TRY(launch(*lens, a_lo, a_hi, dxe, dze, n_e, dxf, dzf, n_f, dtt, dal, 0, n_e, S.a->stream));
     S.download(tt, dtt, tot);
     S.download(alpha_out, dal, tot);
     HIP_TRY(S.finish());
@@ -222,13 +236,15 @@ int rtus_release(int device)
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess) guard.prev = cur;
     for (int d = (device < 0 ? 0 : device); d < (device < 0 ? (n < kMaxDevices ? n : kMaxDevices) : device + 1); ++d) {
-        Arena& a = g_arena[d];
-        std::lock_guard<std::mutex> lk(a.mu);
-        if (!a.dev && !a.stream && !a.pin) continue;
-        HIP_TRY(hipSetDevice(d));
-        if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); a.stream = nullptr; }
-        if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; a.cap = 0; }
-        if (a.pin) { (void)hipHostFree(a.pin); a.pin = nullptr; }
+        for (int sl = 0; sl < kMaxSlots; ++sl) {
+            Arena& a = g_arena[d][sl];
+            std::lock_guard<std::mutex> lk(a.mu);
+            if (!a.dev && !a.stream && !a.pin) continue;
+            HIP_TRY(hipSetDevice(d));
+            if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); a.stream = nullptr; }
+            if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; a.cap = 0; }
+            if (a.pin) { (void)hipHostFree(a.pin); a.pin = nullptr; }
+        }
     }
     return RTUS_OK;
 }
@@ -245,8 +261,10 @@ int rtus_device_count(int* count)
 int rtus_selftest(const rtus_lens* lens, int n_rays, long long n_math, unsigned long long* counts, int device)
 {
     if (!lens || !counts || n_rays < 8 || n_math < 0 || n_math > (1ll << 36)) return RTUS_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(device));
-    LAUNCH_TRY(rtus_selftest_run(*lens, n_rays, n_math, counts, (hipStream_t)0));
+    Session S;                                       // validates `device`, restores the caller's device, the arena's own stream
+    int st = S.open(device, 0);
+    if (st) return st;
+    LAUNCH_TRY(rtus_selftest_run(*lens, n_rays, n_math, counts, S.a->stream));
     return RTUS_OK;
 }
 
@@ -601,7 +619,7 @@ int rtus_tt_lens_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, co
 {
     int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
     if (st) return st;
-    LAUNCH_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+    LAUNCH_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out, 0, n_e,
                                     (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -612,7 +630,7 @@ int rtus_tt_lens_f32_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi
 {
     int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
     if (st) return st;
-    LAUNCH_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out,
+    LAUNCH_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_alpha_out, 0, n_e,
                                     (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -629,6 +647,231 @@ int rtus_tt_lens_f32(const rtus_lens* lens, double alpha_lo, double alpha_hi, co
 {
     return lens_host<float>(lens, alpha_lo, alpha_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, device,
                             rtus_launch_tt_lens_f32);
+}
+
+// ---------------------------------------------------------------------------- row shards of a table, several devices
+int rtus_table_rows_per_block(long long n_rows_total, int n_f, int elem_bytes)
+{
+    if (n_rows_total <= 0 || n_f <= 0 || (elem_bytes != 4 && elem_bytes != 8)) return RTUS_ERR_INVALID_ARG;
+    const int eb = rtus_rows_per_block(n_rows_total, n_f, 1, elem_bytes);
+    return eb < 1 ? RTUS_ERR_UNSUPPORTED : eb;
+}
+
+long long rtus_shard_rows(long long n_rows_total, int n_f, int elem_bytes, int n_shards)
+{
+    if (n_shards <= 0) return RTUS_ERR_INVALID_ARG;
+    const int eb = rtus_table_rows_per_block(n_rows_total, n_f, elem_bytes);
+    if (eb < 0) return eb;
+    const long long per = (n_rows_total + n_shards - 1) / n_shards;
+    return (per + eb - 1) / eb * eb;
+}
+
+static int check_rows(int n_rows, long long row0, long long n_rows_total)
+{
+    if (n_rows <= 0 || row0 < 0 || n_rows_total < row0 + n_rows || n_rows_total > 65535LL * 64) return RTUS_ERR_INVALID_ARG;
+    return RTUS_OK;
+}
+
+int rtus_tt_layers_rows_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze, int n_rows,
+                            long long row0, long long n_rows_total, const double* d_xf, const double* d_zf, int n_f, double* d_tt,
+                            void* stream)
+{
+    int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
+    LAUNCH_TRY(rtus_launch_tt_layers_rows(z_if, c, n_if, d_xe, d_ze, n_rows, (int)row0, n_rows_total, d_xf, d_zf, n_f, d_tt,
+                                       (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tt_lens_rows_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const double* d_xe, const double* d_ze, int n_rows,
+                          long long row0, long long n_rows_total, const double* d_xf, const double* d_zf, int n_f, double* d_tt,
+                          double* d_alpha_out, void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
+    LAUNCH_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt, d_alpha_out, (int)row0,
+                                    n_rows_total, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_tt_lens_f32_rows_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* d_xe, const float* d_ze, int n_rows,
+                              long long row0, long long n_rows_total, const float* d_xf, const float* d_zf, int n_f, float* d_tt,
+                              float* d_alpha_out, void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
+    LAUNCH_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt, d_alpha_out, (int)row0,
+                                    n_rows_total, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+}   // extern "C" (the multi-device host entries share a template)
+
+// One host-buffer call spread over several devices: the table's rows in contiguous blocks (multiples of the table's rows per
+// workgroup: every row comes out with the bits the one-device call gives it), one arena + stream per listed device, every
+// device copying its block straight into the caller's rows.  No exchange between the devices: a host result needs none.
+template <typename R, typename Launch>
+static int table_multi(const R* xe, const R* ze, int n_e, const R* xf, const R* zf, int n_f, R* tt, const int* devices, int n_dev,
+                       Launch launch)
+{
+    if (!devices || n_dev <= 0 || n_dev > 64) return RTUS_ERR_INVALID_ARG;
+    const long long per = rtus_shard_rows(n_e, n_f, (int)sizeof(R), n_dev);
+    if (per < 0) return (int)per;
+    std::vector<Session> S(n_dev);
+    std::vector<int> live(n_dev, 0);
+    int st = RTUS_OK;
+    for (int i = 0; i < n_dev && st == RTUS_OK; ++i) {                 // uploads + launches: asynchronous on each device's stream
+        const long long lo = per * i < n_e ? per * i : n_e, hi = lo + per < n_e ? lo + per : n_e;
+        if (hi <= lo) continue;
+        int slot = 0;
+        for (int j = 0; j < i; ++j) slot += devices[j] == devices[i];
+        const size_t rows = (size_t)(hi - lo), tot = rows * n_f;
+        if ((st = S[i].open(devices[i], 2 * al256(sizeof(R) * rows) + 2 * al256(sizeof(R) * (size_t)n_f) + al256(sizeof(R) * tot), slot))) break;
+        R *dxe, *dze, *dxf, *dzf;
+        S[i].upload(dxe, xe + lo, rows);
+        S[i].upload(dze, ze + lo, rows);
+        S[i].upload(dxf, xf, (size_t)n_f);
+        S[i].upload(dzf, zf, (size_t)n_f);
+        R* dtt = S[i].template take<R>(tot);
+        hipError_t e = S[i].flush();
+        if (e == hipSuccess) { (void)hipGetLastError(); e = launch(dxe, dze, (int)rows, (int)lo, dxf, dzf, dtt, S[i].a->stream); }
+        if (e != hipSuccess) { st = hip_fail(e); break; }
+        S[i].download(tt + (size_t)lo * n_f, dtt, tot);
+        live[i] = 1;
+    }
+    // results back: one host thread per device (a device-to-pageable-host copy occupies its caller; the links are independent)
+    std::vector<hipError_t> err(n_dev, hipSuccess);
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_dev; ++i)
+        if (live[i]) th.emplace_back([&, i] { (void)hipSetDevice(S[i].dev_index); err[i] = S[i].finish(); });
+    if (live[0]) { (void)hipSetDevice(S[0].dev_index); err[0] = S[0].finish(); }
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n_dev; ++i) if (st == RTUS_OK && err[i] != hipSuccess) st = hip_fail(err[i]);
+    return st;
+}
+
+// ---- RCCL, bound at run time (dlopen: librtus.so does not depend on it; a process that already holds PyTorch's librccl
+// gets that one) — only the *_multi_dev reassembly needs it
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct Rccl {
+    void* h = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    std::mutex mu;
+    std::vector<int> devs;               // device list of the cached communicators
+    std::vector<ncclComm_t> comms;
+    bool load()
+    {
+        if (h) return true;
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8;   // ncclDataType_t (nccl.h)
+}   // namespace
+
+// Each listed device solves its row block INTO its own copy of the (padded) table, d_tt[i] + lo n_f; with `gather` the blocks are
+// then exchanged in place by one ncclAllGather per device (single-process communicators, ncclCommInitAll: RCCL over xGMI), so
+// every device ends up with the whole table; without it the table stays sharded.  Asynchronous on the given streams.
+template <typename R, typename Launch>
+static int table_multi_dev(const R* const* d_xe, const R* const* d_ze, int n_e, int n_f, R* const* d_tt, const int* devices, int n_dev,
+                           void* const* streams, int gather, Launch launch)
+{
+    if (!d_xe || !d_ze || !d_tt || !devices || !streams || n_dev <= 0 || n_dev > 64) return RTUS_ERR_INVALID_ARG;
+    const long long per = rtus_shard_rows(n_e, n_f, (int)sizeof(R), n_dev);
+    if (per < 0) return (int)per;
+    DeviceGuard guard;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) guard.prev = cur;
+    for (int i = 0; i < n_dev; ++i) {
+        const long long lo = per * i < n_e ? per * i : n_e, hi = lo + per < n_e ? lo + per : n_e;
+        if (hi <= lo) continue;
+        if (!d_xe[i] || !d_ze[i] || !d_tt[i]) return RTUS_ERR_INVALID_ARG;
+        HIP_TRY(hipSetDevice(devices[i]));
+        (void)hipGetLastError();
+        HIP_TRY(launch(i, d_xe[i] + lo, d_ze[i] + lo, (int)(hi - lo), (int)lo, d_tt[i] + (size_t)lo * n_f, (hipStream_t)streams[i]));
+    }
+    if (!gather || n_dev == 1) return RTUS_OK;
+    std::lock_guard<std::mutex> lk(g_rccl.mu);
+    if (!g_rccl.load()) return RTUS_ERR_UNSUPPORTED;
+    if (g_rccl.devs != std::vector<int>(devices, devices + n_dev)) {
+        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        g_rccl.comms.assign(n_dev, nullptr);
+        g_rccl.devs.clear();
+        if (g_rccl.CommInitAll(g_rccl.comms.data(), n_dev, devices) != 0) { g_rccl.comms.clear(); return RTUS_ERR_UNSUPPORTED; }
+        g_rccl.devs.assign(devices, devices + n_dev);
+    }
+    int bad = g_rccl.GroupStart();
+    for (int i = 0; i < n_dev && !bad; ++i) {
+        HIP_TRY(hipSetDevice(devices[i]));
+        bad = g_rccl.AllGather(d_tt[i] + (size_t)per * i * n_f, d_tt[i], (size_t)per * n_f, sizeof(R) == 8 ? kNcclFloat64 : kNcclFloat32,
+                               g_rccl.comms[i], (hipStream_t)streams[i]);
+    }
+    bad |= g_rccl.GroupEnd();
+    return bad ? RTUS_ERR_UNSUPPORTED : RTUS_OK;
+}
+
+extern "C" {
+
+int rtus_tt_layers_multi(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e, const double* xf,
+                         const double* zf, int n_f, double* tt, const int* devices, int n_dev)
+{
+    int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
+    if (st) return st;
+    return table_multi<double>(xe, ze, n_e, xf, zf, n_f, tt, devices, n_dev,
+                               [&](const double* dxe, const double* dze, int rows, int row0, const double* dxf, const double* dzf, double* dtt,
+                                   hipStream_t s) { return rtus_launch_tt_layers_rows(z_if, c, n_if, dxe, dze, rows, row0, n_e, dxf, dzf, n_f, dtt, s); });
+}
+
+int rtus_tt_lens_f32_multi(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* xe, const float* ze, int n_e,
+                           const float* xf, const float* zf, int n_f, float* tt, const int* devices, int n_dev)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, xe, ze, n_e, xf, zf, n_f, tt);
+    if (st) return st;
+    return table_multi<float>(xe, ze, n_e, xf, zf, n_f, tt, devices, n_dev,
+                              [&](const float* dxe, const float* dze, int rows, int row0, const float* dxf, const float* dzf, float* dtt,
+                                  hipStream_t s) {
+                                  return rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, dxe, dze, rows, dxf, dzf, n_f, dtt, nullptr, row0, n_e, s);
+                              });
+}
+
+int rtus_tt_layers_multi_dev(const double* z_if, const double* c, int n_if, const double* const* d_xe, const double* const* d_ze, int n_e,
+                             const double* const* d_xf, const double* const* d_zf, int n_f, double* const* d_tt, const int* devices,
+                             int n_dev, void* const* streams, int gather)
+{
+    if (!d_xf || !d_zf || !d_xe || !d_ze || !d_tt || n_dev <= 0) return RTUS_ERR_INVALID_ARG;
+    int st = check_layers(z_if, c, n_if, d_xe[0], d_ze[0], n_e, d_xf[0], d_zf[0], n_f, d_tt[0]);
+    if (st) return st;
+    return table_multi_dev<double>(d_xe, d_ze, n_e, n_f, d_tt, devices, n_dev, streams, gather,
+                                   [&](int i, const double* xe, const double* ze, int rows, int row0, double* tt, hipStream_t s) {
+                                       return rtus_launch_tt_layers_rows(z_if, c, n_if, xe, ze, rows, row0, n_e, d_xf[i], d_zf[i], n_f, tt, s);
+                                   });
+}
+
+int rtus_tt_lens_f32_multi_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* const* d_xe, const float* const* d_ze,
+                               int n_e, const float* const* d_xf, const float* const* d_zf, int n_f, float* const* d_tt,
+                               const int* devices, int n_dev, void* const* streams, int gather)
+{
+    if (!d_xf || !d_zf || !d_xe || !d_ze || !d_tt || n_dev <= 0) return RTUS_ERR_INVALID_ARG;
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe[0], d_ze[0], n_e, d_xf[0], d_zf[0], n_f, d_tt[0]);
+    if (st) return st;
+    return table_multi_dev<float>(d_xe, d_ze, n_e, n_f, d_tt, devices, n_dev, streams, gather,
+                                  [&](int i, const float* xe, const float* ze, int rows, int row0, float* tt, hipStream_t s) {
+                                      return rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, xe, ze, rows, d_xf[i], d_zf[i], n_f, tt, nullptr,
+                                                                     row0, n_e, s);
+                                  });
 }
 
 }   // extern "C"

@@ -29,7 +29,6 @@
 // Layout: tt[e][f], f fastest — each wave stores 512 contiguous bytes; xf/zf loads are coalesced; the
 // per-element data of a workgroup (coordinates, extrapolation weights) sits in LDS and is broadcast to the lanes.
 #include "rtus_device.h"
-#include <stdlib.h>
 
 struct LayerArgs {
     double z_if[RTUS_MAX_LAYERS];      // interface depths (n_if used, +inf beyond)
@@ -43,7 +42,11 @@ struct LayerArgs {
     double* __restrict__ tt;
     uint8_t* __restrict__ iters;
     int n_e, n_f;
-    int eb;                            // elements per workgroup (<= 64)
+    int eb;                            // elements per workgroup (<= 64): a function of the WHOLE table's size, see rtus_table_rows_per_block
+    int row0;                          // index of xe[0] in the whole table when this launch solves a block of its rows (else 0):
+                                       // workgroups cover rows [k eb, (k + 1) eb) of the WHOLE table, so a row is solved with the
+                                       // same predecessors — and comes out with the same bits — whether the table is solved in one
+                                       // launch or in row shards
     // batched entry (rtus_tt_layers_batch): problem b = blockIdx.z uses elements / targets / output shifted by these
     long long e_stride, f_stride, t_stride;   // in elements of the respective arrays (0: shared by all problems)
 };
@@ -260,8 +263,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const double xf = a.xf[f], zf = a.zf[f];
-    const int e0 = blockIdx.y * a.eb;
-    const int ne = min(a.eb, a.n_e - e0);                   // elements of this workgroup (<= 64)
+    const int gb = a.row0 / a.eb + blockIdx.y;              // the workgroup's block of the whole table
+    const int e0 = max(gb * a.eb - a.row0, 0);              // ... in this launch's rows (a shard that starts inside a block keeps its tail)
+    const int ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;   // elements of this workgroup (<= 64)
 
     // ---- per-element records: the first wave works them out, one element per lane ----------------------
     if (threadIdx.x < 64) {
@@ -349,9 +353,29 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     }
 }
 
+// Elements (table rows) per workgroup: as many as possible (predictor + set-up reuse: the first four elements of a workgroup
+// start Newton cold) while keeping >= ~4 waves per SIMD; 64 once that still leaves two full rounds of 8 waves per SIMD (measured
+// on BASELINE config 3: 32 -> 64 elements per workgroup = -4.5 % time; on config 2: 8 is the optimum).  A function of the
+// WHOLE table (n_rows_total x n_f, x n_batch problems), never of the launch: row shards of a table use the table's value.
+int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_bytes)
+{
+    const long long wave_solves = (long long)((n_f + 63) / 64) * n_rows_total * n_batch;
+    int eb = (int)(wave_solves / (1024LL * 4));
+    eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
+    if (wave_solves >= 1024LL * 16 * 64) eb = 64;
+#ifdef RTUS_EXP_EB                                          // experiment builds only (scripts/ab_planar.py)
+    eb = RTUS_EXP_EB < 1 ? 1 : (RTUS_EXP_EB > 64 ? 64 : RTUS_EXP_EB);
+#endif
+    while ((n_rows_total + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
+    if ((unsigned long long)eb * (unsigned long long)n_f * (unsigned)elem_bytes >= 0xffffffffull)   // row offsets inside a block are 32-bit
+        eb = (int)(0xffffffffull / ((unsigned long long)n_f * (unsigned)elem_bytes));
+    return eb;
+}
+
 static hipError_t launch_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                 const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int n_batch,
-                                long long e_stride, long long f_stride, long long t_stride, hipStream_t s)
+                                long long e_stride, long long f_stride, long long t_stride, int row0, long long n_rows_total,
+                                hipStream_t s)
 {
     LayerArgs a;
     for (int i = 0; i < RTUS_MAX_LAYERS; ++i) a.z_if[i] = i < n_if ? z_if[i] : INFINITY;
@@ -359,22 +383,11 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
     a.n_e = n_e; a.n_f = n_f;
     a.e_stride = e_stride; a.f_stride = f_stride; a.t_stride = t_stride;
-    // elements per workgroup: as many as possible (predictor + set-up reuse: the first four elements of a workgroup
-    // start Newton cold) while keeping >= ~4 waves per SIMD; 64 once that still leaves two full rounds of 8 waves per
-    // SIMD (measured on BASELINE config 3: 32 -> 64 elements per workgroup = -4.5 % time; on config 2: 8 is the optimum)
-    const long long wave_solves = (long long)((n_f + 63) / 64) * n_e * n_batch;
-    int eb = (int)(wave_solves / (1024LL * 4));
-    eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
-    if (wave_solves >= 1024LL * 16 * 64) eb = 64;
-    static const char* const eb_override = getenv("RTUS_EB");   // experiments only (scripts/ab_planar.py)
-    if (eb_override) eb = atoi(eb_override);
-    while ((n_e + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
-    if ((unsigned long long)eb * (unsigned long long)n_f * 8ull >= 0xffffffffull) {   // row offsets inside a block are 32-bit
-        eb = (int)(0xffffffffull / ((unsigned long long)n_f * 8ull));
-        if (eb < 1 || (n_e + eb - 1) / eb > 65535) return hipErrorInvalidValue;
-    }
+    const int eb = rtus_rows_per_block(n_rows_total, n_f, n_batch, 8);
+    if (eb < 1 || (n_rows_total + eb - 1) / eb > 65535) return hipErrorInvalidValue;
+    a.row0 = row0;
     a.eb = eb;
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + eb - 1) / eb, n_batch), block(RTUS_BLOCK);
+    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (row0 + n_e - 1) / eb - row0 / eb + 1, n_batch), block(RTUS_BLOCK);
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false>), grid, block, 0, s, a); break;
@@ -390,7 +403,16 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
                                  double* tt, uint8_t* iters, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, 0, n_e, s);
+}
+
+// rows [row0, row0 + n_e) of a table of n_rows_total rows: the same bits as the whole table's launch gives those rows when
+// row0 is a multiple of rtus_rows_per_block(n_rows_total, n_f, 1, 8)
+hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                                      int row0, long long n_rows_total, const double* xf, const double* zf, int n_f, double* tt,
+                                      hipStream_t s)
+{
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, row0, n_rows_total, s);
 }
 
 // n_batch independent problems of one shape and one medium in ONE launch (several apertures and / or target sets):
@@ -399,5 +421,5 @@ hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int 
                                        int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
                                        long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, 0, n_e, s);
 }

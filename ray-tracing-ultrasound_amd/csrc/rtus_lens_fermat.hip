@@ -26,6 +26,7 @@ template <typename R> struct LensFermatArgs {
     R* __restrict__ tt;
     R* __restrict__ alpha_out;   // nullable
     int n_e, n_f, eb;
+    int row0;                // index of xe[0] in the whole table (row shards: workgroups stay aligned to the table's blocks, see rtus_fermat.hip)
     int poly_trig;           // 1: [a_lo, a_hi] lies inside [-1, 1] rad -> sin/cos by polynomial, no range reduction
 };
 
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const R xf = a.xf[f], zf = a.zf[f];
-    const int e0 = blockIdx.y * a.eb, ne = min(a.eb, a.n_e - e0);
+    const int gb = a.row0 / a.eb + blockIdx.y;              // the workgroup's block of the whole table
+    const int e0 = max(gb * a.eb - a.row0, 0), ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int el = min(e0 + lane, a.n_e - 1);
@@ -336,9 +338,11 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     }
 }
 
+int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_bytes);   // rtus_fermat.hip
+
 template <typename R>
 static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, const R* xe, const R* ze, int n_e,
-                              const R* xf, const R* zf, int n_f, R* tt, R* alpha_out, hipStream_t s)
+                              const R* xf, const R* zf, int n_f, R* tt, R* alpha_out, int row0, long long n_rows_total, hipStream_t s)
 {
     const LensK kk = make_lens_k(L);
     LensFermatArgs<R> k;
@@ -348,16 +352,10 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     k.xe = xe; k.ze = ze; k.xf = xf; k.zf = zf; k.tt = tt; k.alpha_out = alpha_out;
     k.n_e = n_e; k.n_f = n_f;
     k.poly_trig = (a_lo >= -1.0 && a_hi <= 1.0) ? 1 : 0;
-    const long long wave_solves = (long long)((n_f + 63) / 64) * n_e;
-    int eb = (int)(wave_solves / (1024LL * 4));
-    k.eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
-    if (wave_solves >= 1024LL * 16 * 64) k.eb = 64;         // large tables: halves the cold starts per solve (cf. rtus_fermat.hip)
-    while ((n_e + k.eb - 1) / k.eb > 65535 && k.eb < 64) ++k.eb;   // grid.y limit (eb <= 64: one lane per element)
-    if ((unsigned long long)k.eb * (unsigned long long)n_f * sizeof(R) >= 0xffffffffull) {   // row offsets inside a block are 32-bit
-        k.eb = (int)(0xffffffffull / ((unsigned long long)n_f * sizeof(R)));
-        if (k.eb < 1 || (n_e + k.eb - 1) / k.eb > 65535) return hipErrorInvalidValue;
-    }
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (n_e + k.eb - 1) / k.eb);
+    k.eb = rtus_rows_per_block(n_rows_total, n_f, 1, (int)sizeof(R));   // of the WHOLE table: row shards reproduce its bits
+    if (k.eb < 1 || (n_rows_total + k.eb - 1) / k.eb > 65535) return hipErrorInvalidValue;
+    k.row0 = row0;
+    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (row0 + n_e - 1) / k.eb - row0 / k.eb + 1);
     const bool poly = k.poly_trig != 0, wa = alpha_out != nullptr;
     if (poly && wa) hipLaunchKernelGGL((rtus_tt_lens_kernel<R, true, true>), grid, dim3(RTUS_BLOCK), 0, s, k);
     else if (poly) hipLaunchKernelGGL((rtus_tt_lens_kernel<R, true, false>), grid, dim3(RTUS_BLOCK), 0, s, k);
@@ -368,14 +366,14 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
-                                   double* alpha_out, hipStream_t s)
+                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s)
 {
-    return launch_lens<double>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, s);
+    return launch_lens<double>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, s);
 }
 
 hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi, const float* xe, const float* ze,
                                    int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
-                                   hipStream_t s)
+                                   int row0, long long n_rows_total, hipStream_t s)
 {
-    return launch_lens<float>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, s);
+    return launch_lens<float>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, s);
 }

@@ -21,8 +21,9 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t=None):
+    """the current stream of the tensor's device (of the current device without a tensor)"""
+    return torch.cuda.current_stream(None if t is None else t.device).cuda_stream
 
 
 class ShootPlan:
@@ -107,8 +108,11 @@ def match_dev(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, out=None):
     return out
 
 
-def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
-    """Fermat travel times through horizontal layers; z_if/c are small HOST sequences."""
+def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None):
+    """Fermat travel times through horizontal layers; z_if/c are small HOST sequences.
+
+    row0 / n_rows_total: xe, ze are rows [row0, row0 + len(xe)) of a table of n_rows_total rows (rtus_tt_layers_rows_dev): with
+    row0 a multiple of ``rows_per_block(n_rows_total, n_f)`` the block comes out with the bits the whole table's launch gives it."""
     import numpy as np
     z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
     c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
@@ -123,9 +127,44 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None):
     _chk(out, "out")
     if out.numel() != n_e * n_f:
         raise ValueError("out has the wrong size")
+    if n_rows_total is not None:
+        if iters is not None:
+            raise ValueError("iters is a whole-table diagnostic")
+        st = _lib.lib().rtus_tt_layers_rows_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
+                                                n_e, int(row0), int(n_rows_total), _p(xf), _p(zf), n_f, _p(out), _stream())
+        _lib.check(st, "rtus_tt_layers_rows_dev")
+        return out
     st = _lib.lib().rtus_tt_layers_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
                                        _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
     _lib.check(st, "rtus_tt_layers_dev")
+    return out
+
+
+def rows_per_block(n_rows_total, n_f, dtype=torch.float64):
+    """Rows the table kernels solve per workgroup for a table of this size: shard boundaries that are multiples of it
+    reproduce the one-launch table bit for bit (rtus_table_rows_per_block)."""
+    r = _lib.lib().rtus_table_rows_per_block(int(n_rows_total), int(n_f), 8 if dtype == torch.float64 else 4)
+    if r < 0:
+        _lib.check(r, "rtus_table_rows_per_block")
+    return int(r)
+
+
+def tt_lens_rows_dev(xe, ze, xf, zf, out, *, params: Params = None, alpha_lo=None, alpha_hi=None, row0=0, n_rows_total=None):
+    """Curved-lens table rows [row0, row0 + len(xe)) of an n_rows_total-row table, fp64 or fp32 by the tensors' dtype."""
+    from .api import ALPHA_MAX
+    p = _resolve(params)
+    f64 = xe.dtype == torch.float64
+    for t, n in ((xe, "xe"), (ze, "ze"), (xf, "xf"), (zf, "zf"), (out, "out")):
+        _chk(t, n, xe.dtype)
+    n_e, n_f = xe.numel(), xf.numel()
+    if ze.numel() != n_e or zf.numel() != n_f or out.numel() != n_e * n_f:
+        raise ValueError("xe/ze, xf/zf and out must pair up")
+    fn = _lib.lib().rtus_tt_lens_rows_dev if f64 else _lib.lib().rtus_tt_lens_f32_rows_dev
+    lens = p.lens()
+    st = fn(C.byref(lens), -ALPHA_MAX if alpha_lo is None else float(alpha_lo), ALPHA_MAX if alpha_hi is None else float(alpha_hi),
+            _p(xe), _p(ze), n_e, int(row0), int(n_e if n_rows_total is None else n_rows_total), _p(xf), _p(zf), n_f, _p(out), None,
+            _stream())
+    _lib.check(st, "rtus_tt_lens_rows_dev")
     return out
 
 
@@ -186,8 +225,10 @@ def tfm_dev(fmc, fs, tt_tx, tt_rx=None, t0=0.0, out=None):
     if out is None:
         out = torch.empty(n_f, dtype=torch.float32, device=fmc.device)
     _chk(out, "out", torch.float32)
+    if out.numel() != n_f or not (out.device == fmc.device == tt_tx.device == tt_rx.device):
+        raise ValueError("out must hold n_focal float32 values on the device of fmc / tt_tx / tt_rx")
     st = _lib.lib().rtus_tfm_dev(_p(fmc), fmc.shape[0], fmc.shape[1], fmc.shape[2], float(fs), float(t0), _p(tt_tx), _p(tt_rx), n_f,
-                                 _p(out), _stream())
+                                 _p(out), _stream(fmc))
     _lib.check(st, "rtus_tfm_dev")
     return out
 
@@ -196,7 +237,7 @@ class LayersPlan:
     """Pre-bound ``rtus_tt_layers_dev`` call for repeated solves of one shape: ``run()`` is a single
     ctypes call (no argument checking, no allocation, no sync) — capturable in a hipGraph."""
 
-    def __init__(self, z_if, c, xe, ze, xf, zf, out=None, iters=None):
+    def __init__(self, z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None):
         import numpy as np
         self.z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
         self.c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
@@ -215,6 +256,9 @@ class LayersPlan:
         self._fn = _lib.lib().rtus_tt_layers_dev
         self._args = [self.z_if.ctypes.data if self.z_if.size else None, self.c.ctypes.data, self.z_if.size,
                       _p(xe), _p(ze), self.n_e, _p(xf), _p(zf), self.n_f, _p(self.out), _p(iters)]
+        if n_rows_total is not None:              # a row block of a larger table (rtus_tt_layers_rows_dev)
+            self._fn = _lib.lib().rtus_tt_layers_rows_dev
+            self._args = self._args[:6] + [int(row0), int(n_rows_total)] + self._args[6:10]
 
     def run(self, stream=None):
         st = self._fn(*self._args, _stream() if stream is None else stream)

@@ -10,11 +10,16 @@ import torch
 import torch.distributed as dist
 
 
-def row_shard(n_rows: int, world: int, rank: int):
-    """(lo, hi, rows_per_rank): rank owns rows [lo, hi) of the padded world*rows_per_rank layout."""
-    if n_rows <= 0 or world <= 0 or not (0 <= rank < world):
+def row_shard(n_rows: int, world: int, rank: int, align: int = 1):
+    """(lo, hi, rows_per_rank): rank owns rows [lo, hi) of the padded world*rows_per_rank layout.
+
+    align: rows_per_rank is rounded up to a multiple of it.  With align = the table kernels' rows per workgroup
+    (device.rows_per_block) every shard starts on a block boundary of the whole table, and the sharded table is bit for bit
+    the one-GPU table (a row is always solved in the same workgroup with the same predecessors)."""
+    if n_rows <= 0 or world <= 0 or not (0 <= rank < world) or align <= 0:
         raise ValueError("bad shard request")
     per = -(-n_rows // world)
+    per = -(-per // align) * align
     lo = min(rank * per, n_rows)
     hi = min(lo + per, n_rows)
     return lo, hi, per
@@ -26,12 +31,13 @@ class RowShardedMatrix:
     block is its own buffer (send and receive buffers of the collective never alias); with one rank it is a
     view of the matrix and no collective runs."""
 
-    def __init__(self, n_rows, n_cols, *, dtype=torch.float64, device="cuda", slots=2, group=None):
+    def __init__(self, n_rows, n_cols, *, dtype=torch.float64, device="cuda", slots=2, group=None, align=1):
         self.group = group
+        self.align = int(align)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
-        self.lo, self.hi, self.per = row_shard(self.n_rows, self.world, self.rank)
+        self.lo, self.hi, self.per = row_shard(self.n_rows, self.world, self.rank, self.align)
         self.full = [torch.zeros((self.world * self.per, self.n_cols), dtype=dtype, device=device)
                      for _ in range(slots)]
         self.shard = ([f[:self.per] for f in self.full] if self.world == 1 else
@@ -71,10 +77,10 @@ class RowShardedMatrix:
         return self.full[slot][:self.n_rows]
 
 
-def sharded_rows(n_rows, n_cols, row_solver, *, dtype=torch.float64, device="cuda", group=None):
+def sharded_rows(n_rows, n_cols, row_solver, *, dtype=torch.float64, device="cuda", group=None, align=1):
     """Generic row-sharded table: ``row_solver(lo, hi, out)`` fills rows [lo, hi) of the table into ``out``
     ([hi-lo, n_cols] view of this rank's block); the blocks are then all-gathered in place on every rank."""
-    m = RowShardedMatrix(n_rows, n_cols, dtype=dtype, device=device, slots=1, group=group)
+    m = RowShardedMatrix(n_rows, n_cols, dtype=dtype, device=device, slots=1, group=group, align=align)
     n_own = m.hi - m.lo
     if n_own > 0:
         row_solver(m.lo, m.hi, m.local(0)[:n_own])
@@ -82,40 +88,36 @@ def sharded_rows(n_rows, n_cols, row_solver, *, dtype=torch.float64, device="cud
     return m.matrix(0)
 
 
-def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=None):
-    """Element x focal travel-time matrix computed by row shards on all ranks, gathered everywhere.
+def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=None, align=None):
+    """Element x focal travel-time matrix computed by row shards on all ranks, gathered everywhere — bit for bit the one-GPU
+    table: shards start on the table's workgroup-block boundaries and the kernel is told where its rows sit in the table.
 
     xe, ze, xf, zf: torch tensors on this rank's device holding the FULL element / focal lists.
-    ``solver(z_if, c, xe_shard, ze_shard, xf, zf, out)`` defaults to the HIP kernel; the CPU (gloo)
-    tests inject the oracle here — the product default never touches it.
+    ``solver(z_if, c, xe_shard, ze_shard, xf, zf, out=, row0=, n_rows_total=)`` defaults to the HIP kernel; the CPU (gloo)
+    tests inject the oracle here (with ``align`` given) — the product default never touches it.
     """
+    n_rows = xe.numel()
     if solver is None:
-        from .device import tt_layers_dev as solver
+        from .device import rows_per_block, tt_layers_dev as solver
+        align = rows_per_block(n_rows, xf.numel()) if align is None else align
 
     def rows(lo, hi, out):
-        solver(z_if, c, xe[lo:hi].contiguous(), ze[lo:hi].contiguous(), xf, zf, out=out)
-    return sharded_rows(xe.numel(), xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group)
+        solver(z_if, c, xe[lo:hi].contiguous(), ze[lo:hi].contiguous(), xf, zf, out=out, row0=lo, n_rows_total=n_rows)
+    return sharded_rows(n_rows, xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group, align=1 if align is None else align)
 
 
 def travel_time_lens_sharded(xe, ze, xf, zf, *, params=None, alpha_lo=None, alpha_hi=None, group=None):
     """BASELINE config 4 across ranks: curved-lens Fermat table (fp64 or fp32 by the tensors' dtype), tx rows
-    sharded, reassembled by the all-gather."""
-    import ctypes as C
-    from . import _lib
-    from .api import ALPHA_MAX, _resolve
-    p = _resolve(params)
-    lens = p.lens()
-    fn = _lib.lib().rtus_tt_lens_dev if xe.dtype == torch.float64 else _lib.lib().rtus_tt_lens_f32_dev
-    a_lo = -ALPHA_MAX if alpha_lo is None else float(alpha_lo)
-    a_hi = ALPHA_MAX if alpha_hi is None else float(alpha_hi)
+    sharded on the table's workgroup-block boundaries (bit for bit the one-GPU table), reassembled by the all-gather."""
+    from .device import rows_per_block, tt_lens_rows_dev
+    n_rows = xe.numel()
 
     def rows(lo, hi, out):
         xs, zs = xe[lo:hi].contiguous(), ze[lo:hi].contiguous()
-        st = fn(C.byref(lens), a_lo, a_hi, xs.data_ptr(), zs.data_ptr(), hi - lo, xf.data_ptr(), zf.data_ptr(),
-                xf.numel(), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rtus_tt_lens_dev")
+        tt_lens_rows_dev(xs, zs, xf, zf, out, params=params, alpha_lo=alpha_lo, alpha_hi=alpha_hi, row0=lo, n_rows_total=n_rows)
         torch.cuda.current_stream().synchronize()          # xs / zs must outlive the launch
-    return sharded_rows(xe.numel(), xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group)
+    return sharded_rows(n_rows, xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group,
+                        align=rows_per_block(n_rows, xf.numel(), xe.dtype))
 
 
 def col_shard(n_cols: int, world: int, rank: int):

@@ -22,14 +22,14 @@ def _free_port():
     return p
 
 
-def _oracle_solver(z_if, c, xe, ze, xf, zf, out):
+def _oracle_solver(z_if, c, xe, ze, xf, zf, out, row0=0, n_rows_total=None):
     from oracle import cport
     tt = cport.tt_layers_newton(z_if, c, xe.numpy(), ze.numpy(), xf.numpy(), zf.numpy())
     out.copy_(torch.from_numpy(tt))
     return out
 
 
-def _worker(rank, world, port, n_e, q):
+def _worker(rank, world, port, n_e, q, align=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,9 +40,9 @@ def _worker(rank, world, port, n_e, q):
     ze = torch.zeros(n_e, dtype=torch.float64)
     xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 24), np.linspace(0.025, 0.065, 20))
     xf, zf = torch.from_numpy(xs.ravel().copy()), torch.from_numpy(zs.ravel().copy())
-    full = d.travel_time_layers_sharded([0.02], [2330.0, 1483.0], xe, ze, xf, zf, solver=_oracle_solver)
+    full = d.travel_time_layers_sharded([0.02], [2330.0, 1483.0], xe, ze, xf, zf, solver=_oracle_solver, align=align)
     # async double-buffered variant as bench.py uses it
-    m = d.RowShardedMatrix(n_e, xf.numel(), device="cpu", slots=2)
+    m = d.RowShardedMatrix(n_e, xf.numel(), device="cpu", slots=2, align=align)
     for slot in (0, 1):
         own = m.hi - m.lo
         if own:
@@ -55,13 +55,13 @@ def _worker(rank, world, port, n_e, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_e", [16, 13])          # 13: rows not divisible by the world size -> padding
-def test_sharded_matrix_equals_single_process(n_e):
+@pytest.mark.parametrize("n_e,align", [(16, 1), (13, 1), (13, 4)])   # 13: rows not divisible by the world size -> padding;
+def test_sharded_matrix_equals_single_process(n_e, align):          # align 4: shards on workgroup-block boundaries (8 + 5 rows)
     from oracle import cport
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_e, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_e, q, align)) for r in range(2)]
     for p in procs:
         p.start()
     full, ok, shard = q.get()
@@ -74,7 +74,8 @@ def test_sharded_matrix_equals_single_process(n_e):
     assert full.shape == ref.shape
     assert np.array_equal(full, ref)            # byte-identical to the 1-process result
     assert ok
-    assert shard == (0, -(-n_e // 2), -(-n_e // 2))
+    per = -(-(-(-n_e // 2)) // align) * align
+    assert shard == (0, per, per)
 
 
 def test_row_shard_partition():

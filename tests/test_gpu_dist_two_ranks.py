@@ -1,8 +1,9 @@
 """GPU: the sharded travel-time tables with the REAL HIP solvers across two ranks.  This pool gives one GPU per
 box, so both ranks share cuda:0 and exchange over gloo (RCCL needs one device per rank); what is checked is the
-product's sharding + gather code path end to end: the reassembled matrix equals the one-process result (to the
-solver's own 1e-16 s: a row solved in a different workgroup starts Newton from a different predictor), for the
-planar-layer solver (fp64) and the curved-lens solver (fp32), with a row count that needs padding."""
+product's sharding + gather code path end to end: the reassembled matrix is BYTE-IDENTICAL to the one-process result
+(shards start on the table's workgroup-block boundaries and the kernels are told where their rows sit in the table, so a
+row is solved in the same workgroup with the same predecessors either way), for the planar-layer solver (fp64) and the
+curved-lens solver (fp32), with row counts that need padding."""
 import os
 import socket
 import sys
@@ -35,16 +36,25 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = import_module("ray-tracing-ultrasound_amd.dist")
     t = lambda a, dt=np.float64: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device="cuda")
-    n_e = 37                                                   # not divisible by 2 -> one pad row
+    n_e = 37                                                   # not divisible by 2 -> pad rows
     xe = (np.arange(n_e) - (n_e - 1) / 2) * 0.6e-3
     xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 40), np.linspace(0.025, 0.065, 30))
     full = d.travel_time_layers_sharded([0.02], [2330.0, 1483.0], t(xe), t(np.zeros(n_e)), t(xs.ravel()), t(zs.ravel()))
+    # a table big enough for multi-row workgroups (8 rows per block here): 150 rows -> shards of 80 + 70
+    n_b = 150
+    xb = (np.arange(n_b) - (n_b - 1) / 2) * 0.25e-3
+    xg, zg = np.meshgrid(np.linspace(-0.02, 0.02, 160), np.linspace(0.026, 0.066, 128))
+    big = d.travel_time_layers_sharded([0.010, 0.025], [2330.0, 1483.0, 5900.0], t(xb), t(np.zeros(n_b)), t(xg.ravel()), t(zg.ravel()))
     xl, zl = np.meshgrid(np.linspace(-0.004, 0.004, 33), np.linspace(0.03, 0.07, 21))
     lens = d.travel_time_lens_sharded(t(xe * 0.1, np.float32), t(np.full(n_e, D_PLANE), np.float32),
                                       t(xl.ravel(), np.float32), t(zl.ravel(), np.float32), params=rtus.Params())
     torch.cuda.synchronize()
+    xl2, zl2 = np.meshgrid(np.linspace(-0.004, 0.004, 256), np.linspace(0.03, 0.07, 128))
+    lens_big = d.travel_time_lens_sharded(t(xb * 0.1, np.float32), t(np.full(n_b, D_PLANE), np.float32),
+                                          t(xl2.ravel(), np.float32), t(zl2.ravel(), np.float32), params=rtus.Params())
+    torch.cuda.synchronize()
     if rank == 0:
-        q.put((full.cpu().numpy(), lens.cpu().numpy()))
+        q.put((full.cpu().numpy(), lens.cpu().numpy(), big.cpu().numpy(), lens_big.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +67,7 @@ def test_two_ranks_sharded_tables_equal_single_process(rtus):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, lens = q.get()
+    full, lens, big, lens_big = q.get()
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
@@ -66,14 +76,26 @@ def test_two_ranks_sharded_tables_equal_single_process(rtus):
     xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 40), np.linspace(0.025, 0.065, 30))
     one = rtus.travel_time_layers([0.02], [2330.0, 1483.0], xe, np.zeros(n_e), xs.ravel(), zs.ravel())
     assert full.shape == one.shape
-    # rows computed in a different workgroup composition start Newton from a different predictor: results agree
-    # to the solver's own accuracy, not bit for bit
-    assert np.max(np.abs(full - one)) < 1e-16
+    assert np.array_equal(full, one)                       # byte-identical (SURVEY section 7 test plan)
     xl, zl = np.meshgrid(np.linspace(-0.004, 0.004, 33), np.linspace(0.03, 0.07, 21))
     one32 = rtus.travel_time_lens(xe * 0.1, np.full(n_e, D_PLANE), xl.ravel(), zl.ravel(), params=rtus.Params(),
                                   dtype=np.float32)
     assert lens.shape == one32.shape and lens.dtype == np.float32
-    assert np.max(np.abs(lens.astype(np.float64) - one32.astype(np.float64))) < 1e-10
+    assert np.array_equal(lens, one32)
+    # multi-row workgroups: the shard boundary (row 80) is a block boundary of the whole table
+    n_b = 150
+    xb = (np.arange(n_b) - (n_b - 1) / 2) * 0.25e-3
+    xg, zg = np.meshgrid(np.linspace(-0.02, 0.02, 160), np.linspace(0.026, 0.066, 128))
+    from importlib import import_module
+    import torch
+    dev = import_module("ray-tracing-ultrasound_amd.device")
+    assert dev.rows_per_block(n_b, xg.size) > 1
+    one_b = rtus.travel_time_layers([0.010, 0.025], [2330.0, 1483.0, 5900.0], xb, np.zeros(n_b), xg.ravel(), zg.ravel())
+    assert np.array_equal(big, one_b)
+    xl2, zl2 = np.meshgrid(np.linspace(-0.004, 0.004, 256), np.linspace(0.03, 0.07, 128))
+    assert dev.rows_per_block(n_b, xl2.size, torch.float32) > 1
+    one_l = rtus.travel_time_lens(xb * 0.1, np.full(n_b, D_PLANE), xl2.ravel(), zl2.ravel(), params=rtus.Params(), dtype=np.float32)
+    assert np.array_equal(lens_big, one_l)
 
 
 def _run_bench_two_ranks(extra_args):
