@@ -62,7 +62,8 @@ def test_multi_argument_errors(rtus):
     with pytest.raises(rtus.RtusError):
         rtus.travel_time_layers(*a, devices=[99])
     with pytest.raises(rtus.RtusError):
-        rtus.travel_time_layers(*a, devices=[0] * 5)          # more entries of one device than arenas per device
+        rtus.travel_time_layers(*_planar(10, 8), devices=[0] * 5)   # five live shards on one device: more than its four arenas
+    assert np.array_equal(rtus.travel_time_layers(*a, devices=[0] * 5), rtus.travel_time_layers(*a))   # (8 rows: the fifth shard is empty)
 
 
 def test_multi_dev_variant_one_device_no_exchange(rtus):
