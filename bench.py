@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="planar workloads, graph mode: capture the K steps round-robin on this many streams, each with its "
                          "own output buffer (default 1: K back-to-back launches on one stream)")
+    ap.add_argument("--tier", default="taup", choices=["taup", "accurate"],
+                    help="planar workloads: accuracy tier of the solver — taup (RTUS_TT_TAUP_TAIL: the travel time from the tau-p form, "
+                         "<= 6e-11 relative at worst; the measured max |dt| is in the line) or accurate (the library's default tier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     args = ap.parse_args(argv)
@@ -341,8 +344,9 @@ def main(argv=None):
                 assert st == 0
         else:
             xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
-            plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)[:n_e]) for b in range(slots)]
-            kernel = f"rtus_tt_layers_kernel<{len(W['c'])}, false>"
+            taup = args.tier == "taup"
+            plans = [dev_api.LayersPlan(W["z_if"], W["c"], xe, ze, xf, zf, out=m.local(b)[:n_e], taup=taup) for b in range(slots)]
+            kernel = f"rtus_tt_layers_kernel<{len(W['c'])}, false, {'true' if taup else 'false'}, false>"
 
             def launch(b):
                 plans[b].run()
@@ -441,8 +445,12 @@ def main(argv=None):
             "solves_per_step_per_gpu": units_per_step,
             "solves_per_step_all_gpus": total_units_per_step,
             "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64)"}.get(
-                wl, "fp64 results; the planar solver's Newton PRE-iteration runs on the fp32 pipe, the result comes from an "
-                    "fp64 evaluation + Fermat expansion (measured max |dt| vs the long-double oracle: see `accuracy`)"
+                wl, ("fp64 results, tier RTUS_TT_TAUP_TAIL: Newton PRE-iteration on the fp32 pipe, the travel time from the tau-p form "
+                     "p X + sum (h/c) cos(theta) in fp64 (stationary in p) + its second-order term from the fp32 residual — <= 6e-11 "
+                     "relative by construction, measured max |dt| vs the long-double oracle: see `accuracy`; the library's default tier "
+                     "(fp64 residual, <= 1e-13 relative) is timed in extra.cfg3_planar_accurate_tier" if args.tier == "taup" else
+                     "fp64 results, default tier: Newton PRE-iteration on the fp32 pipe, the result from an fp64 evaluation + Fermat "
+                     "expansion (measured max |dt| vs the long-double oracle: see `accuracy`)")
                 if wl in PLANAR else "fp64, reference-compatible arithmetic"),
             "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather_step else
                                                        ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
@@ -701,6 +709,39 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                  "G_rays_per_s_kernel_only": round(rays / (ms * 1e-3) / 1e9, 2)}
         res[kind + ("_fastmath" if fast else "")] = entry
+    # --- BASELINE configs[2] again: the library's default accuracy tier, and the aperture handed over in random order ------
+    W3 = planar_inputs("cfg3_planar", 0, 1)
+    out3 = torch.empty((W3["n_e"], W3["n_f"]), dtype=torch.float64, device=dev)
+    a3 = [t64(W3[k]) for k in ("xe", "ze", "xf", "zf")]
+    n3 = W3["n_e"] * W3["n_f"]
+    plan_acc = dev_api.LayersPlan(W3["z_if"], W3["c"], *a3, out=out3)
+    for _ in range(3):
+        plan_acc.run()
+    torch.cuda.synchronize()
+    timed = Timed(torch, lambda s: plan_acc.run(), 50)
+    dta, msa = timed.run(lambda: None)
+    res["cfg3_planar_accurate_tier"] = {"Mrays_per_s": round(n3 * 50 / dta / 1e6, 1), "ms_per_launch": round(msa, 5),
+                                        "hbm_frac": round((n3 * 8 + 2 * (W3["n_e"] + W3["n_f"]) * 8) / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "rtus_tt_layers_dev, default tier (fp64 residual + Fermat expansion, <= 1e-13 relative)"}
+    perm = np.random.default_rng(3).permutation(W3["n_e"])
+    xsh, zsh = t64(W3["xe"][perm]), t64(W3["ze"][perm])
+    ws = torch.empty(int(rtus.lib().rtus_tt_layers_sort_workspace_bytes(W3["n_e"])), dtype=torch.uint8, device=dev)
+    shuffled = lambda taup: dev_api.tt_layers_sorted_dev(W3["z_if"], W3["c"], xsh, zsh, a3[2], a3[3], out=out3, ws=ws, taup=taup)
+    plain_sh = lambda: dev_api.tt_layers_dev(W3["z_if"], W3["c"], xsh, zsh, a3[2], a3[3], out=out3)
+    ent = {}
+    for name, fn in (("sorted_entry_taup", lambda: shuffled(True)), ("sorted_entry_accurate", lambda: shuffled(False)), ("plain_entry_accurate", plain_sh)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        tm = Timed(torch, lambda s: fn(), 20)
+        dts, mss = tm.run(lambda: None)
+        ent[name] = {"Mrays_per_s": round(n3 * 20 / dts / 1e6, 1), "ms_per_launch": round(mss, 5)}
+        del tm
+    ent["note"] = ("the 256 elements in random order.  rtus_tt_layers_sorted_dev sorts the aperture on the device (one more launch, "
+                   "O(n^2) rank) and stores each row where it belongs; plain_entry = rtus_tt_layers_dev on the same order: the predictor "
+                   "has no neighbours to extrapolate from (cold-started Newton)")
+    res["cfg3_planar_shuffled"] = ent
+    del out3, plan_acc, timed
     # --- BASELINE configs[1] (the small planar launch: 17 MB of results, one 4-wave round per SIMD) ---------------
     W = planar_inputs("cfg2_planar", 0, 1)
     out2 = torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device=dev)

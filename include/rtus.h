@@ -213,6 +213,12 @@ int rtus_ray_hits(const double *land_x, int n_batch, int n_rays, const double *x
  * single round of 4 waves per SIMD) no longer pays a launch ramp and drain of its own.
  * ---------------------------------------------------------------------------------------- */
 #define RTUS_MAX_LAYERS 8
+/* Accuracy tier of the planar solver (flags of rtus_tt_layers_rows_dev / rtus_tt_layers_multi*).  0: the travel time from an fp64
+ * evaluation at the Newton iterate + its second-order Fermat expansion in an fp64 residual: <= 1e-13 relative (measured 3e-18 s
+ * on BASELINE config 3).  RTUS_TT_TAUP_TAIL: from the tau-p form T = p X + sum (h_i/c_i) cos(theta_i), stationary in p, with the
+ * second-order term from the fp32 residual: four fp64 instructions fewer per solve, <= 6e-11 relative (~2e-15 s) at worst,
+ * ~3e-14 typically — six orders inside the 1e-9 s bar of the north-star. */
+#define RTUS_TT_TAUP_TAIL 0x1u
 
 int rtus_tt_layers_dev(const double *z_if, const double *c, int n_if,
                        const double *d_xe, const double *d_ze, int n_e,
@@ -228,6 +234,18 @@ int rtus_tt_layers(const double *z_if, const double *c, int n_if,
                    const double *xe, const double *ze, int n_e,
                    const double *xf, const double *zf, int n_f,
                    double *tt, uint8_t *iters, int device);
+
+/* The aperture in ANY order.  The kernel starts each solve from the four previous elements of its workgroup's block, which pays
+ * (1 evaluation instead of ~4.5) when consecutive elements are neighbours in space at one depth.  rtus_tt_layers_dev takes the
+ * elements as they come; this entry sorts them on the device by (depth, position) first and stores each row where it belongs
+ * (d_workspace: rtus_tt_layers_sort_workspace_bytes(n_e) bytes, 256-byte aligned; n_e <= 32768).  The result of an element does
+ * not depend on the order the aperture was handed over in.  The host-buffer twin rtus_tt_layers does the same by itself (it sorts
+ * on the host); flags: RTUS_TT_TAUP_TAIL or 0. */
+size_t rtus_tt_layers_sort_workspace_bytes(int n_e);
+int rtus_tt_layers_sorted_dev(const double *z_if, const double *c, int n_if,
+                              const double *d_xe, const double *d_ze, int n_e,
+                              const double *d_xf, const double *d_zf, int n_f,
+                              double *d_tt, void *d_workspace, size_t workspace_bytes, unsigned flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element x focal-point Fermat travel times through the reference's CURVED lens surface
@@ -287,7 +305,7 @@ long long rtus_shard_rows(long long n_rows_total, int n_f, int elem_bytes, int n
 
 int rtus_tt_layers_rows_dev(const double *z_if, const double *c, int n_if,
                             const double *d_xe, const double *d_ze, int n_rows, long long row0, long long n_rows_total,
-                            const double *d_xf, const double *d_zf, int n_f, double *d_tt, void *stream);
+                            const double *d_xf, const double *d_zf, int n_f, double *d_tt, unsigned flags, void *stream);
 int rtus_tt_lens_rows_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
                           const double *d_xe, const double *d_ze, int n_rows, long long row0, long long n_rows_total,
                           const double *d_xf, const double *d_zf, int n_f, double *d_tt, double *d_alpha_out, void *stream);

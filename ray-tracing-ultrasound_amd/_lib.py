@@ -111,11 +111,15 @@ def lib():
     for name in ("rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32"):
         getattr(L, name).restype = ip
     ll = C.c_longlong
+    L.rtus_tt_layers_sort_workspace_bytes.argtypes = [ip]
+    L.rtus_tt_layers_sort_workspace_bytes.restype = C.c_size_t
+    L.rtus_tt_layers_sorted_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, C.c_size_t, C.c_uint, vp]
+    L.rtus_tt_layers_sorted_dev.restype = ip
     L.rtus_table_rows_per_block.argtypes = [ll, ip, ip]
     L.rtus_table_rows_per_block.restype = ip
     L.rtus_shard_rows.argtypes = [ll, ip, ip, ip]
     L.rtus_shard_rows.restype = ll
-    L.rtus_tt_layers_rows_dev.argtypes = [dp, dp, ip, dp, dp, ip, ll, ll, dp, dp, ip, dp, vp]
+    L.rtus_tt_layers_rows_dev.argtypes = [dp, dp, ip, dp, dp, ip, ll, ll, dp, dp, ip, dp, C.c_uint, vp]
     L.rtus_tt_lens_rows_dev.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, ll, ll, dp, dp, ip, dp, dp, vp]
     L.rtus_tt_lens_f32_rows_dev.argtypes = L.rtus_tt_lens_rows_dev.argtypes
     L.rtus_tt_layers_multi.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, C.POINTER(C.c_int), ip]
@@ -144,6 +148,6 @@ EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_
            "rtus_tt_lens_dev", "rtus_tt_lens", "rtus_tt_lens_f32_dev", "rtus_tt_lens_f32",
            "rtus_solve_workspace_bytes", "rtus_solve_dev", "rtus_solve",
            "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm",
-           "rtus_table_rows_per_block", "rtus_shard_rows", "rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev",
+           "rtus_tt_layers_sort_workspace_bytes", "rtus_tt_layers_sorted_dev", "rtus_table_rows_per_block", "rtus_shard_rows", "rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev",
            "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi", "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev",
            "rtus_tt_lens_f32_multi_dev")

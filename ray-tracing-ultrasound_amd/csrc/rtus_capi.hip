@@ -3,8 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <algorithm>
 #include <dlfcn.h>
 #include <mutex>
+#include <numeric>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -33,8 +35,12 @@ hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int 
                                        long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s);
 hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                       int row0, long long n_rows_total, const double* xf, const double* zf, int n_f, double* tt,
-                                      hipStream_t s);
+                                      unsigned flags, hipStream_t s);
 int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_bytes);
+size_t rtus_layers_sort_ws_bytes(int n_e);
+hipError_t rtus_launch_tt_layers_sorted(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                                        const double* xf, const double* zf, int n_f, double* tt, void* ws, const int* presorted_row_of,
+                                        unsigned flags, hipStream_t s);
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
@@ -523,24 +529,59 @@ int rtus_tt_layers_batch_dev(const double* z_if, const double* c, int n_if, cons
     return RTUS_OK;
 }
 
+size_t rtus_tt_layers_sort_workspace_bytes(int n_e) { return n_e > 0 ? rtus_layers_sort_ws_bytes(n_e) : 0; }
+
+#define RTUS_SORT_MAX_ELEMENTS 32768                 /* the device-side rank is O(n^2) compares */
+int rtus_tt_layers_sorted_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze, int n_e,
+                              const double* d_xf, const double* d_zf, int n_f, double* d_tt, void* d_workspace, size_t workspace_bytes,
+                              unsigned flags, void* stream)
+{
+    int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
+    if (st) return st;
+    if (flags & ~RTUS_TT_TAUP_TAIL) return RTUS_ERR_INVALID_ARG;
+    if (n_e > RTUS_SORT_MAX_ELEMENTS) return RTUS_ERR_UNSUPPORTED;
+    if (!d_workspace || ((uintptr_t)d_workspace & 255) || workspace_bytes < rtus_layers_sort_ws_bytes(n_e)) return RTUS_ERR_WORKSPACE;
+    LAUNCH_TRY(rtus_launch_tt_layers_sorted(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_workspace, nullptr, flags,
+                                         (hipStream_t)stream));
+    return RTUS_OK;
+}
+
 int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                    const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int device)
 {
     int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
     if (st) return st;
     const size_t tot = (size_t)n_e * n_f;
+    // the aperture in (depth, position) order — the order the predictor of the kernel wants; the coordinates are host memory
+    // here, so the sort is the host's: an aperture that arrives in that order (the usual case) goes through unchanged
+    std::vector<int> order;
+    std::vector<double> sx, sz;
+    bool sorted = true;
+    for (int i = 1; i < n_e && sorted; ++i) sorted = ze[i - 1] < ze[i] || (ze[i - 1] == ze[i] && xe[i - 1] <= xe[i]);
+    if (!sorted && !iters) {
+        order.resize(n_e);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ze[a] < ze[b] || (ze[a] == ze[b] && xe[a] < xe[b]); });
+        sx.resize(n_e); sz.resize(n_e);
+        for (int i = 0; i < n_e; ++i) { sx[i] = xe[order[i]]; sz[i] = ze[order[i]]; }
+    }
+    const bool perm = !order.empty();
     Session S;
-    if ((st = S.open(device, 2 * al256(8 * (size_t)n_e) + 2 * al256(8 * (size_t)n_f) + al256(8 * tot) + (iters ? al256(tot) : 0))))
+    if ((st = S.open(device, 2 * al256(8 * (size_t)n_e) + 2 * al256(8 * (size_t)n_f) + al256(8 * tot) + (iters ? al256(tot) : 0) +
+                                 (perm ? al256(4 * (size_t)n_e) : 0))))
         return st;
     double *dxe, *dze, *dxf, *dzf;
-    S.upload(dxe, xe, n_e);
-    S.upload(dze, ze, n_e);
+    int* drow = nullptr;
+    S.upload(dxe, perm ? sx.data() : xe, n_e);
+    S.upload(dze, perm ? sz.data() : ze, n_e);
     S.upload(dxf, xf, n_f);
     S.upload(dzf, zf, n_f);
+    if (perm) S.upload(drow, (const int*)order.data(), n_e);
     double* dtt = S.take<double>(tot);
     uint8_t* dit = iters ? S.take<uint8_t>(tot) : nullptr;
     HIP_TRY(S.flush());
-    LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, S.a->stream));
+    if (perm) LAUNCH_TRY(rtus_launch_tt_layers_sorted(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, nullptr, drow, 0u, S.a->stream));
+    else LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, S.a->stream));
     S.download(tt, dtt, tot);
     S.download(iters, dit, tot);
     HIP_TRY(S.finish());
@@ -674,11 +715,12 @@ static int check_rows(int n_rows, long long row0, long long n_rows_total)
 
 int rtus_tt_layers_rows_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze, int n_rows,
                             long long row0, long long n_rows_total, const double* d_xf, const double* d_zf, int n_f, double* d_tt,
-                            void* stream)
+                            unsigned flags, void* stream)
 {
     int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
     if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
-    LAUNCH_TRY(rtus_launch_tt_layers_rows(z_if, c, n_if, d_xe, d_ze, n_rows, (int)row0, n_rows_total, d_xf, d_zf, n_f, d_tt,
+    if (flags & ~RTUS_TT_TAUP_TAIL) return RTUS_ERR_INVALID_ARG;
+    LAUNCH_TRY(rtus_launch_tt_layers_rows(z_if, c, n_if, d_xe, d_ze, n_rows, (int)row0, n_rows_total, d_xf, d_zf, n_f, d_tt, flags,
                                        (hipStream_t)stream));
     return RTUS_OK;
 }
@@ -832,7 +874,7 @@ int rtus_tt_layers_multi(const double* z_if, const double* c, int n_if, const do
     if (st) return st;
     return table_multi<double>(xe, ze, n_e, xf, zf, n_f, tt, devices, n_dev,
                                [&](const double* dxe, const double* dze, int rows, int row0, const double* dxf, const double* dzf, double* dtt,
-                                   hipStream_t s) { return rtus_launch_tt_layers_rows(z_if, c, n_if, dxe, dze, rows, row0, n_e, dxf, dzf, n_f, dtt, s); });
+                                   hipStream_t s) { return rtus_launch_tt_layers_rows(z_if, c, n_if, dxe, dze, rows, row0, n_e, dxf, dzf, n_f, dtt, 0u, s); });
 }
 
 int rtus_tt_lens_f32_multi(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* xe, const float* ze, int n_e,
@@ -856,7 +898,7 @@ int rtus_tt_layers_multi_dev(const double* z_if, const double* c, int n_if, cons
     if (st) return st;
     return table_multi_dev<double>(d_xe, d_ze, n_e, n_f, d_tt, devices, n_dev, streams, gather,
                                    [&](int i, const double* xe, const double* ze, int rows, int row0, double* tt, hipStream_t s) {
-                                       return rtus_launch_tt_layers_rows(z_if, c, n_if, xe, ze, rows, row0, n_e, d_xf[i], d_zf[i], n_f, tt, s);
+                                       return rtus_launch_tt_layers_rows(z_if, c, n_if, xe, ze, rows, row0, n_e, d_xf[i], d_zf[i], n_f, tt, 0u, s);
                                    });
 }
 

@@ -43,6 +43,7 @@ struct LayerArgs {
     uint8_t* __restrict__ iters;
     int n_e, n_f;
     int eb;                            // elements per workgroup (<= 64): a function of the WHOLE table's size, see rtus_table_rows_per_block
+    const int* __restrict__ row_of;    // PERM kernels: output row of element i (the elements arrive sorted by (ze, xe), see rtus_rank_kernel)
     int row0;                          // index of xe[0] in the whole table when this launch solves a block of its rows (else 0):
                                        // workgroups cover rows [k eb, (k + 1) eb) of the WHOLE table, so a row is solved with the
                                        // same predecessors — and comes out with the same bits — whether the table is solved in one
@@ -69,7 +70,7 @@ struct __attribute__((aligned(16))) ElemRec {
     double xe;
     int info;               // bits 0-2: previous elements usable as history (0..4); bit 3: depth differs from the previous
                             // element's (layer set-up needed); bits 8..: length of the run of 4-history elements starting here
-    int pad;
+    int row;                // PERM: the element's output row
 };
 
 // Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
@@ -78,6 +79,7 @@ template <int NL>
 struct Lane {
     double hr0, hc0, hr[NL], kk[NL], hc[NL], inv_cm;       // slots 1 .. NL-1 of the arrays are used
     float hr0f, hrf[NL], kkf[NL], rs0f, rhmf, asymf;       // fp32 copies for the Newton loop, cold-start bounds
+    float inv_cmf;                                         // (tau-p tail: scales its second-order term)
     float tau;                                             // relative step below which a lane stops (+inf: target not below the element)
     float rS3;                                             // 1 / X'(q) of the latest evaluation
 };
@@ -136,6 +138,7 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
     L.rs0f = __builtin_amdgcn_rcpf(s0f) * (1.0f - 4e-6f);
     L.rhmf = __builtin_amdgcn_rcpf(hmf) * (1.0f - 4e-6f);
     L.asymf = asf * (1.0f + 4e-6f);
+    L.inv_cmf = (float)L.inv_cm;
     L.hc0 = valid ? L.hc0 : NAN;                    // target not below the element: T = NaN falls out of the sums
     L.rS3 = 0.0f;
 }
@@ -144,7 +147,9 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
 // (h1 the latest); the new one is returned.  FAST: the element has four usable predecessors — the cubic extrapolation
 // is within 3e-4 of the root for all but ~1e-4 of the solves, so the lower-bound clamp is only formed when a lane
 // of the wave asks for a second Newton evaluation.
-template <int NL, bool ITERS, bool FAST>
+// TAUP: the travel time from the tau-p form T = p X + sum (h_i / c_i) cos(theta_i) instead of T(q) + its Fermat expansion — see
+// the tail below.
+template <int NL, bool ITERS, bool FAST, bool TAUP>
 __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, const ElemRec& R, int hist, double xf,
                                             float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f,
                                             __amdgpu_buffer_rsrc_t rs, unsigned soff)
@@ -158,10 +163,10 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     // the stopping threshold.  Lanes whose target is not below the element carry garbage
     // through the arithmetic (never a step: tau = +inf) and get NaN at the store.
     const float Xf = (float)X;
-    float y[NL], dq = 0.0f;                                 // dq: the (small, untaken) Newton step of the last evaluation
+    float y[NL], dq = 0.0f, dXf = 0.0f;                     // dq: the (small, untaken) Newton step of the last evaluation, dXf its residual
     int it = 0;
     // one evaluation of X(q), X'(q) on the fp32 pipe -> Newton step dq; y[] = the rsqrt seeds of this q
-    auto eval = [&](float qq) {
+    auto eval = [&](float qq, bool second = false) {
         const float q2 = qq * qq;
         float S1 = L.hr0f, S3 = L.hr0f;                     // slot 0: k = 0, y = 1
 #pragma unroll
@@ -171,8 +176,12 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
             S1 += hw;
             S3 = fmaf(hw, y[i] * y[i], S3);
         }
-        L.rS3 = __builtin_amdgcn_rcpf(S3);
-        dq = fmaf(-S1, qq, Xf) * L.rS3;
+        // 1 / X'(q).  tau-p tier on a four-history run: X' moves by well under 1 % from one element to the next, so ONE Newton step
+        // from the previous element's reciprocal (two FMAs, error = that change squared: < 1e-4) replaces the v_rcp_f32 (8.2 issue cycles)
+        if (TAUP && FAST && !second) L.rS3 = fmaf(fmaf(-S3, L.rS3, 1.0f), L.rS3, L.rS3);
+        else L.rS3 = __builtin_amdgcn_rcpf(S3);
+        dXf = fmaf(-S1, qq, Xf);
+        dq = dXf * L.rS3;
     };
     // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
     auto lower_bound = [&]() { return fmaxf(fmaxf(Xf * L.rs0f, (Xf - L.asymf) * L.rhmf), 0.0f); };
@@ -180,7 +189,7 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     // take it, so y[] stays the y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
     auto newton = [&](float& q, float lb) {
         for (int trip = 0; trip < 64; ++trip) {             // wave-uniform trip count, ballot exit
-            eval(q);
+            eval(q, true);
             const bool big = fabsf(dq) > L.tau * q;         // tau = +inf on lanes without a path: never a step
             if (!__builtin_amdgcn_ballot_w64(big)) break;
             q = big ? fmaxf(q + dq, lb) : q;
@@ -215,18 +224,39 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     const double a1 = 1.0 + q2;
     const float us = __builtin_amdgcn_rsqf(fmaf(q, q, 1.0f));   // u to 1e-7 on the fp32 pipe: seed + 2nd-order term
     const double u = rsqrt_refine(a1, (double)us);
-    double A1 = L.hr0, ST = L.hc0;                          // slot 0: w = 1
+    double T;
+    if (!TAUP) {
+        double A1 = L.hr0, ST = L.hc0;                      // slot 0: w = 1
 #pragma unroll
-    for (int i = 1; i < NL; ++i) {
-        const double w = rsqrt_refine(fma(L.kk[i], q2, 1.0), (double)y[i]);
-        A1 = fma(L.hr[i], w, A1);
-        ST = fma(L.hc[i], w, ST);
+        for (int i = 1; i < NL; ++i) {
+            const double w = rsqrt_refine(fma(L.kk[i], q2, 1.0), (double)y[i]);
+            A1 = fma(L.hr[i], w, A1);
+            ST = fma(L.hc[i], w, ST);
+        }
+        const double dXr = fma(-A1, qd, X);
+        // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
+        // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
+        const float s2 = (0.5f * us) * (us * L.rS3);
+        T = u * fma(L.inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
+    } else {
+        // tau-p form (the faster accuracy tier, RTUS_TT_TAUP_TAIL): with p = sin(theta)/c = q u / cm and cos(theta_i) =
+        // u sqrt(1 + k_i q^2), F(p) = p X + sum (h_i/c_i) cos(theta_i) is STATIONARY in p at the ray (dF/dp = X - X(p)): evaluated
+        // at the Newton iterate its first-order error vanishes by itself — no second weighted sum (X(q) in fp64), no fp64
+        // residual — and T = F + (1/2)(dp/dX) dXr^2 with the residual the fp32 evaluation already has:
+        // (1/2)(dp/dX) dXr^2 = (1/2) u^3 / (cm X') dXr^2 = (1/2) u^3 (dq dXr) / cm.  The fp32 residual carries ~2e-7 X of
+        // rounding, so that term — and T — is off by up to (dq/q) 2e-7 T: 6e-11 T at the stopping threshold, ~3e-14 T typically
+        // (the accurate tier: 1e-13 T at most).  Four fp64 instructions fewer per solve (24 against 28 with three layers).
+        double ST = L.hc0;                                  // slot 0: cos(theta_0) / u = 1
+#pragma unroll
+        for (int i = 1; i < NL; ++i) {
+            const double d = fma(L.kk[i], q2, 1.0), yi = (double)y[i];
+            const double g = d * yi;                        // sqrt(d) from the seed ...
+            const double t = fma(-g, g, d) * yi;            // ... and one Newton step: sqrt(d) = g + t / 2 (error ~1e-14)
+            ST = fma(L.hc[i], fma(t, 0.5, g), ST);
+        }
+        const float Sf = (0.5f * us) * (us * us) * (L.inv_cmf * (dq * dXf));
+        T = fma(u, fma(qd * L.inv_cm, X, ST), (double)Sf);
     }
-    const double dXr = fma(-A1, qd, X);
-    // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
-    // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
-    const float s2 = (0.5f * us) * (us * L.rS3);
-    const double T = u * fma(L.inv_cm, dXr * fma((double)s2, dXr, qd), a1 * ST);
     // store through the workgroup's buffer descriptor (base: its first output row, extent: its block of rows): the
     // element's row enters as the scalar offset, each lane supplies a 32-bit byte offset (no 64-bit per-lane address
     // arithmetic, no descriptor rebuilt per row); lanes beyond the last target have redone the last target and store
@@ -249,7 +279,9 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
 // the workgroup works them out once for element e0 + t and parks them in LDS.
 // The predictor is only a guess: iterates are clamped to the rigorous lower bound of the root,
 // from which Newton is monotone, so convergence never depends on the elements being evenly spaced.
-template <int NL, bool ITERS>   // NL = number of layers the medium has (n_if + 1)
+// NL = number of layers the medium has (n_if + 1); TAUP: the tau-p tail (accuracy tier); PERM: the elements arrive sorted by
+// (depth, position) and element i's row of the table is a.row_of[i] — an aperture handed over in any order gets the predictor.
+template <int NL, bool ITERS, bool TAUP = false, bool PERM = false>
 __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_tt_layers_kernel(LayerArgs a)
 {
     __shared__ ElemRec rec[64];
@@ -310,7 +342,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         ElemRec r;
         r.w1 = w1; r.w2 = w2; r.w3 = w3; r.w4 = w4; r.xe = x0;
         r.info = m | (hist == 0 ? 8 : 0) | (run << 8);
-        r.pad = 0;
+        r.row = PERM ? a.row_of[el] : 0;
         rec[lane] = r;
     }
     __syncthreads();
@@ -326,6 +358,15 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.tt + o, 0, (unsigned)ne * row_bytes, 0x00020000);
     unsigned so = 0;                                         // li * row_bytes (< 2^32: the launcher sizes eb for it)
     int li = 0;
+    // where element `idx` of the block is stored: its row inside the workgroup's block of rows (one descriptor, the row as the
+    // instruction's scalar offset) or, PERM, a descriptor of the row it belongs to (a few scalar instructions per element)
+    auto dest_rs = [&](int idx) {
+        if (!PERM) return rs;
+        const size_t row = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row);
+        return __builtin_amdgcn_make_buffer_rsrc(a.tt + row * nf, 0, row_bytes, 0x00020000);
+    };
+    auto dest_so = [&](unsigned off) { return PERM ? 0u : off; };
+    auto dest_o = [&](int idx, size_t off) { return PERM ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row) * nf : off; };
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
         if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
@@ -337,20 +378,55 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         if (run4 > 0) {
             // four-history run, unrolled by four so that the history rotates through its registers without moves
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, o, (unsigned)f, rs, so);
-                qc = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, o + nf, (unsigned)f, rs, so + row_bytes);
-                qb = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, o + 2 * nf, (unsigned)f, rs, so + 2 * row_bytes);
-                qa = solve_elem<NL, ITERS, true>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, o + 3 * nf, (unsigned)f, rs, so + 3 * row_bytes);
+                qd = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r), dest_so(so));
+                qc = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1), dest_so(so + row_bytes));
+                qb = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2), dest_so(so + 2 * row_bytes));
+                qa = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3), dest_so(so + 3 * row_bytes));
                 o += 4 * nf; so += 4 * row_bytes;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, o, (unsigned)f, rs, so);
+            const float qn = solve_elem<NL, ITERS, false, TAUP>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li), dest_so(so));
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf; so += row_bytes;
             ++li;
         }
     }
+}
+
+// Order of the aperture.  The predictor extrapolates from the four previous elements of a workgroup's block, which only works when
+// consecutive elements are neighbours in space at one depth; an aperture handed over in another order fell back to cold-started
+// Newton (~4.5 evaluations instead of 1).  rtus_rank_kernel sorts it by (depth, position, index) — every element counts the
+// elements before it in that order (O(n^2) compares through LDS tiles: 65 k for 256 elements) and drops its coordinates and its
+// index at that rank — and the PERM kernels store each row where it belongs.  Keys are the IEEE bits made monotone, so the order
+// is total whatever the values.
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(256) void rtus_rank_kernel(const double* __restrict__ xe, const double* __restrict__ ze, int n,
+                                                        double* __restrict__ xs, double* __restrict__ zs, int* __restrict__ row_of)
+{
+    __shared__ unsigned long long kx[256], kz[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const double x = xe[live ? i : n - 1], z = ze[live ? i : n - 1];
+    const unsigned long long mx = order_key(x), mz = order_key(z);
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        kx[threadIdx.x] = order_key(xe[j < n ? j : n - 1]);
+        kz[threadIdx.x] = order_key(ze[j < n ? j : n - 1]);
+        __syncthreads();
+        const int m = min(256, n - j0);
+        for (int t = 0; t < m; ++t) {
+            const unsigned long long ox = kx[t], oz = kz[t];
+            rank += (oz < mz) || (oz == mz && (ox < mx || (ox == mx && j0 + t < i)));
+        }
+        __syncthreads();
+    }
+    if (live) { xs[rank] = x; zs[rank] = z; row_of[rank] = i; }
 }
 
 // Elements (table rows) per workgroup: as many as possible (predictor + set-up reuse: the first four elements of a workgroup
@@ -375,9 +451,10 @@ int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_b
 static hipError_t launch_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                 const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int n_batch,
                                 long long e_stride, long long f_stride, long long t_stride, int row0, long long n_rows_total,
-                                hipStream_t s)
+                                unsigned flags, const int* row_of, hipStream_t s)
 {
     LayerArgs a;
+    a.row_of = row_of;
     for (int i = 0; i < RTUS_MAX_LAYERS; ++i) a.z_if[i] = i < n_if ? z_if[i] : INFINITY;
     for (int i = 0; i <= RTUS_MAX_LAYERS; ++i) { a.c[i] = i <= n_if ? c[i] : 1.0; a.inv_c[i] = 1.0 / a.c[i]; }
     a.n_if = n_if; a.xe = xe; a.ze = ze; a.xf = xf; a.zf = zf; a.tt = tt; a.iters = iters;
@@ -388,9 +465,16 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     a.row0 = row0;
     a.eb = eb;
     const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (row0 + n_e - 1) / eb - row0 / eb + 1, n_batch), block(RTUS_BLOCK);
+#ifdef RTUS_EXP_TAUP_DEFAULT                                // experiment builds only (scripts/ab_planar.py)
+    flags |= RTUS_TT_TAUP_TAIL;
+#endif
+    const bool taup = (flags & RTUS_TT_TAUP_TAIL) != 0;
     switch (n_if + 1) {
-#define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true>), grid, block, 0, s, a); \
-                               else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false>), grid, block, 0, s, a); break;
+#define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, 0, s, a); \
+                               else if (row_of && taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, true>), grid, block, 0, s, a); \
+                               else if (row_of) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, true>), grid, block, 0, s, a); \
+                               else if (taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, false>), grid, block, 0, s, a); \
+                               else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, false>), grid, block, 0, s, a); break;
         RTUS_CASE(1) RTUS_CASE(2) RTUS_CASE(3) RTUS_CASE(4) RTUS_CASE(5) RTUS_CASE(6) RTUS_CASE(7) RTUS_CASE(8)
         RTUS_CASE(9)
 #undef RTUS_CASE
@@ -403,16 +487,16 @@ hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, 
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
                                  double* tt, uint8_t* iters, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, 0, n_e, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, 0, n_e, 0u, nullptr, s);
 }
 
 // rows [row0, row0 + n_e) of a table of n_rows_total rows: the same bits as the whole table's launch gives those rows when
 // row0 is a multiple of rtus_rows_per_block(n_rows_total, n_f, 1, 8)
 hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                       int row0, long long n_rows_total, const double* xf, const double* zf, int n_f, double* tt,
-                                      hipStream_t s)
+                                      unsigned flags, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, row0, n_rows_total, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, row0, n_rows_total, flags, nullptr, s);
 }
 
 // n_batch independent problems of one shape and one medium in ONE launch (several apertures and / or target sets):
@@ -421,5 +505,23 @@ hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int 
                                        int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
                                        long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, 0, n_e, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, 0, n_e, 0u, nullptr, s);
+}
+
+// The whole table with the aperture in ANY order: sorted copies of the coordinates + each element's row in `ws`
+// (rtus_layers_sort_ws_bytes), then the PERM kernel.  `presorted_row_of`: the caller (the host-buffer twin) has sorted on the
+// host and uploaded sorted xe / ze and the row indices itself — no rank launch.
+size_t rtus_layers_sort_ws_bytes(int n_e) { return ((size_t)n_e * 8 + 255) / 256 * 256 * 2 + ((size_t)n_e * 4 + 255) / 256 * 256; }
+hipError_t rtus_launch_tt_layers_sorted(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                                        const double* xf, const double* zf, int n_f, double* tt, void* ws, const int* presorted_row_of,
+                                        unsigned flags, hipStream_t s)
+{
+    if (presorted_row_of)
+        return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, 0, n_e, flags, presorted_row_of, s);
+    const size_t seg = ((size_t)n_e * 8 + 255) / 256 * 256;
+    double* xs = (double*)ws;
+    double* zs = (double*)((char*)ws + seg);
+    int* row_of = (int*)((char*)ws + 2 * seg);
+    hipLaunchKernelGGL(rtus_rank_kernel, dim3((n_e + 255) / 256), dim3(256), 0, s, xe, ze, n_e, xs, zs, row_of);
+    return launch_layers(z_if, c, n_if, xs, zs, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, 0, n_e, flags, row_of, s);
 }

@@ -108,7 +108,10 @@ def match_dev(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, out=None):
     return out
 
 
-def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None):
+TAUP_TAIL = 0x1             # RTUS_TT_TAUP_TAIL: the faster accuracy tier of the planar solver (include/rtus.h)
+
+
+def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None, taup=False):
     """Fermat travel times through horizontal layers; z_if/c are small HOST sequences.
 
     row0 / n_rows_total: xe, ze are rows [row0, row0 + len(xe)) of a table of n_rows_total rows (rtus_tt_layers_rows_dev): with
@@ -127,16 +130,43 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_
     _chk(out, "out")
     if out.numel() != n_e * n_f:
         raise ValueError("out has the wrong size")
-    if n_rows_total is not None:
+    if n_rows_total is not None or taup:
         if iters is not None:
-            raise ValueError("iters is a whole-table diagnostic")
+            raise ValueError("iters is a whole-table diagnostic of the accurate tier")
         st = _lib.lib().rtus_tt_layers_rows_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
-                                                n_e, int(row0), int(n_rows_total), _p(xf), _p(zf), n_f, _p(out), _stream())
+                                                n_e, int(row0), int(n_e if n_rows_total is None else n_rows_total), _p(xf), _p(zf), n_f,
+                                                _p(out), TAUP_TAIL if taup else 0, _stream())
         _lib.check(st, "rtus_tt_layers_rows_dev")
         return out
     st = _lib.lib().rtus_tt_layers_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
                                        _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
     _lib.check(st, "rtus_tt_layers_dev")
+    return out
+
+
+def tt_layers_sorted_dev(z_if, c, xe, ze, xf, zf, out=None, ws=None, taup=False):
+    """The planar table for an aperture handed over in ANY order (rtus_tt_layers_sorted_dev): sorted by (depth, position) on the
+    device, every row stored where it belongs.  ``ws``: optional uint8 workspace tensor to reuse between calls."""
+    import numpy as np
+    z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+    if c.size != z_if.size + 1:
+        raise ValueError("need len(c) == len(z_if) + 1")
+    _chk(xe, "xe"); _chk(ze, "ze"); _chk(xf, "xf"); _chk(zf, "zf")
+    n_e, n_f = xe.numel(), xf.numel()
+    if ze.numel() != n_e or zf.numel() != n_f:
+        raise ValueError("xe/ze and xf/zf must pair up")
+    if out is None:
+        out = torch.empty((n_e, n_f), dtype=torch.float64, device=xe.device)
+    _chk(out, "out")
+    need = int(_lib.lib().rtus_tt_layers_sort_workspace_bytes(n_e))
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.uint8, device=xe.device)
+    if ws.numel() < need or out.numel() != n_e * n_f:
+        raise ValueError("workspace or out too small")
+    st = _lib.lib().rtus_tt_layers_sorted_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze), n_e,
+                                              _p(xf), _p(zf), n_f, _p(out), _p(ws), ws.numel(), TAUP_TAIL if taup else 0, _stream(xe))
+    _lib.check(st, "rtus_tt_layers_sorted_dev")
     return out
 
 
@@ -237,7 +267,7 @@ class LayersPlan:
     """Pre-bound ``rtus_tt_layers_dev`` call for repeated solves of one shape: ``run()`` is a single
     ctypes call (no argument checking, no allocation, no sync) — capturable in a hipGraph."""
 
-    def __init__(self, z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None):
+    def __init__(self, z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_total=None, taup=False):
         import numpy as np
         self.z_if = np.ascontiguousarray(z_if, dtype=np.float64).reshape(-1)
         self.c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
@@ -256,9 +286,10 @@ class LayersPlan:
         self._fn = _lib.lib().rtus_tt_layers_dev
         self._args = [self.z_if.ctypes.data if self.z_if.size else None, self.c.ctypes.data, self.z_if.size,
                       _p(xe), _p(ze), self.n_e, _p(xf), _p(zf), self.n_f, _p(self.out), _p(iters)]
-        if n_rows_total is not None:              # a row block of a larger table (rtus_tt_layers_rows_dev)
+        if n_rows_total is not None or taup:      # a row block of a larger table and / or the tau-p tier (rtus_tt_layers_rows_dev)
             self._fn = _lib.lib().rtus_tt_layers_rows_dev
-            self._args = self._args[:6] + [int(row0), int(n_rows_total)] + self._args[6:10]
+            self._args = self._args[:6] + [int(row0), int(self.n_e if n_rows_total is None else n_rows_total)] + self._args[6:10] + \
+                [TAUP_TAIL if taup else 0]
 
     def run(self, stream=None):
         st = self._fn(*self._args, _stream() if stream is None else stream)

@@ -1,4 +1,4 @@
-"""GPU: the element loop's continuation (start extrapolated from the three previous elements of a workgroup block)
+"""GPU: the element loop's continuation (start extrapolated from the FOUR previous elements of a workgroup block; three in the lens kernel)
 is only a guess — results must not depend on how the aperture is ordered.  Irregular apertures: duplicates,
 reversed / shuffled order, clusters, depth changing inside a block, non-finite coordinates.  Checked against
 the oracle and against one-element launches (no history at all).  Tolerances: 1e-13 s vs the oracle (its own
