@@ -360,13 +360,12 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     int li = 0;
     // where element `idx` of the block is stored: its row inside the workgroup's block of rows (one descriptor, the row as the
     // instruction's scalar offset) or, PERM, a descriptor of the row it belongs to (a few scalar instructions per element)
-    auto dest_rs = [&](int idx) {
+    auto dest_o = [&](int idx, size_t off) { return PERM ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row) * nf : off; };
+    auto dest_rs = [&](int idx, size_t off) {
         if (!PERM) return rs;
-        const size_t row = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row);
-        return __builtin_amdgcn_make_buffer_rsrc(a.tt + row * nf, 0, row_bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(a.tt + dest_o(idx, off), 0, row_bytes, 0x00020000);
     };
     auto dest_so = [&](unsigned off) { return PERM ? 0u : off; };
-    auto dest_o = [&](int idx, size_t off) { return PERM ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row) * nf : off; };
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
         if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
@@ -378,15 +377,15 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         if (run4 > 0) {
             // four-history run, unrolled by four so that the history rotates through its registers without moves
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r), dest_so(so));
-                qc = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1), dest_so(so + row_bytes));
-                qb = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2), dest_so(so + 2 * row_bytes));
-                qa = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3), dest_so(so + 3 * row_bytes));
+                qd = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
+                qc = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                qb = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                qa = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
                 o += 4 * nf; so += 4 * row_bytes;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false, TAUP>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li), dest_so(so));
+            const float qn = solve_elem<NL, ITERS, false, TAUP>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf; so += row_bytes;
             ++li;
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
 // Order of the aperture.  The predictor extrapolates from the four previous elements of a workgroup's block, which only works when
 // consecutive elements are neighbours in space at one depth; an aperture handed over in another order fell back to cold-started
 // Newton (~4.5 evaluations instead of 1).  rtus_rank_kernel sorts it by (depth, position, index) — every element counts the
-// elements before it in that order (O(n^2) compares through LDS tiles: 65 k for 256 elements) and drops its coordinates and its
+// elements before it in that order (O(n^2) compares, a wave per element: 65 k for 256 elements) and drops its coordinates and its
 // index at that rank — and the PERM kernels store each row where it belongs.  Keys are the IEEE bits made monotone, so the order
 // is total whatever the values.
 __device__ __forceinline__ unsigned long long order_key(double v)
@@ -408,25 +407,20 @@ __device__ __forceinline__ unsigned long long order_key(double v)
 __global__ __launch_bounds__(256) void rtus_rank_kernel(const double* __restrict__ xe, const double* __restrict__ ze, int n,
                                                         double* __restrict__ xs, double* __restrict__ zs, int* __restrict__ row_of)
 {
-    __shared__ unsigned long long kx[256], kz[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n;
-    const double x = xe[live ? i : n - 1], z = ze[live ? i : n - 1];
+    // one WAVE per element: 64 compares per step, a ballot count each (a thread per element looping over all the others is a
+    // chain of n dependent steps on one wave: 33 us for 256 elements)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;                                       // wave-uniform
+    const double x = xe[i], z = ze[i];
     const unsigned long long mx = order_key(x), mz = order_key(z);
     int rank = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        kx[threadIdx.x] = order_key(xe[j < n ? j : n - 1]);
-        kz[threadIdx.x] = order_key(ze[j < n ? j : n - 1]);
-        __syncthreads();
-        const int m = min(256, n - j0);
-        for (int t = 0; t < m; ++t) {
-            const unsigned long long ox = kx[t], oz = kz[t];
-            rank += (oz < mz) || (oz == mz && (ox < mx || (ox == mx && j0 + t < i)));
-        }
-        __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long ox = order_key(xe[min(j, n - 1)]), oz = order_key(ze[min(j, n - 1)]);
+        const bool before = j < n && ((oz < mz) || (oz == mz && (ox < mx || (ox == mx && j < i))));
+        rank += __popcll(__ballot(before));
     }
-    if (live) { xs[rank] = x; zs[rank] = z; row_of[rank] = i; }
+    if (lane == 0) { xs[rank] = x; zs[rank] = z; row_of[rank] = i; }
 }
 
 // Elements (table rows) per workgroup: as many as possible (predictor + set-up reuse: the first four elements of a workgroup
@@ -522,6 +516,6 @@ hipError_t rtus_launch_tt_layers_sorted(const double* z_if, const double* c, int
     double* xs = (double*)ws;
     double* zs = (double*)((char*)ws + seg);
     int* row_of = (int*)((char*)ws + 2 * seg);
-    hipLaunchKernelGGL(rtus_rank_kernel, dim3((n_e + 255) / 256), dim3(256), 0, s, xe, ze, n_e, xs, zs, row_of);
+    hipLaunchKernelGGL(rtus_rank_kernel, dim3((n_e + 3) / 4), dim3(256), 0, s, xe, ze, n_e, xs, zs, row_of);
     return launch_layers(z_if, c, n_if, xs, zs, n_e, xf, zf, n_f, tt, nullptr, 1, 0, 0, 0, 0, n_e, flags, row_of, s);
 }
