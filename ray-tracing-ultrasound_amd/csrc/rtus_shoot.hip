@@ -184,7 +184,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
     in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];          // main_rt.py:466-467
     in.xa = a.x_a[tx]; in.za = a.z_a[tx];
     in.P = a.curve[r];
-    if (FAST) in.tu = a.tan_u[r]; else in.phis = a.phi_s[r];
+    in.tu = a.tan_u[r];
+    if (!FAST) in.phis = a.phi_s[r];
     in.zf = a.z_f ? a.z_f[r] : a.zf_const;
     RayOut o_;
     trace_ray<FAST>(a, in, o_);

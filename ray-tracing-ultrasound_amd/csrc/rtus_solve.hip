@@ -280,8 +280,8 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
             rtus_sincos(ac, sn, cs);                                     // |alpha| < 8: the bounded-range kernels
             lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
             in.P = make_double2(px, pz);
-            if (FAST) { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
-            else in.phis = rtus_atan2(dz, dx);
+            { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+            if (!FAST) in.phis = rtus_atan2(dz, dx);
             RayOut o;
             trace_ray<FAST>(a, in, o);                                   // all 64 lanes together
             const double fc = o.x_in - xr;

@@ -235,7 +235,7 @@ __device__ __forceinline__ double cap_vertical(double ux, double uz)
 
 // ---- one ray: lens point P (+ its tangent) -> pipe -> lens -> landing ---------------------------
 // Called by all 64 lanes of a wave together (the crossing search is a lock-step walk).
-struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };
+struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };   // phis: compat; tu: both modes
 struct RayOut { double xq, zq, xi, zi, x_in; };
 
 // Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan /
@@ -265,9 +265,20 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     if (!FAST) {
         const double phis = in.phis;
         const double eta = k.eta21;                                     // c2 / c1, host-rounded (the same IEEE division)
-        const double phi_ap = rtus_atan2(za - P.y, xa - P.x);           // :341
-        const double theta_1 = phi_ap - (phis + RTUS_PI_2);             // :267-280 refraction, tuple branch
-        const double sn = eta * rtus_sin(theta_1);
+        double sn;
+        if (eta < 1.0) {
+            // Into the slower medium (wave-uniform; the reference's lens: eta = 0.23) |eta sin(theta_1)| < 1 whatever the ray
+            // does: no total-reflection decision hangs on the last bits of sin(theta_1), and the reference's
+            // sin(atan2(A - P) - (phi_s + pi/2))  (:341, :267-280)  is -(t . v) / |v| with t = (cos phi_s, sin phi_s) the unit
+            // tangent the polyline kernel keeps beside phi_s: a dot product and a reciprocal square root (~12 instructions,
+            // ~1 ulp) for atan2 + sin (~84).  The angle phi_pq is still formed below (the reflection needs it).
+            const double vx = xa - P.x, vz = za - P.y;
+            sn = -eta * (fma(in.tu.x, vx, in.tu.y * vz) * rsqrt_fast(fma(vx, vx, vz * vz)));
+        } else {
+            const double phi_ap = rtus_atan2(za - P.y, xa - P.x);       // :341
+            const double theta_1 = phi_ap - (phis + RTUS_PI_2);         // :267-280 refraction, tuple branch
+            sn = eta * rtus_sin(theta_1);
+        }
         // entering the slower medium |eta sin| stays below 1/2: the wave-uniform test drops asin's second form
         phi_pq = phis - RTUS_PI_2 + (eta < 0.5 ? rtus_asin_small(sn) : rtus_asin(sn));   // :345
         bool steep;
@@ -481,8 +492,28 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         double si, ci;
         rtus_div2(xi, zi, rho, si, ci);
         lens_eval_sc(k, si, ci, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
+#ifdef RTUS_ANGLE_FORM_EXIT                                 // comparison builds: the reference's angle chain for the exit refraction too
         const double phi_last = refract_angle(phi_l, rtus_atan2(ldz, ldx), k.eta12);   // :398
         a3 = rtus_tan(phi_last);                                       // :401
+#else
+        // :398-401  tan(phi_s - pi/2 + asin(eta sin(phi_l - (phi_s + pi/2)))), phi_s = atan2(dz, dx), without forming an angle:
+        // with the unit tangent (cs, ss) = (dx, dz) / |.| and the unit vector of phi_l, (cl, sl) = +-(1, m) / sqrt(1 + m^2) — the
+        // sign is that of cos(phi_l), and phi_l IS known as an angle —
+        //   sin(theta_1) = -cos(phi_l - phi_s) = -(cl cs + sl ss),   s2 = eta sin(theta_1),   c2 = sqrt(1 - s2^2)  (NaN beyond
+        //   the critical angle: the reference's asin of |x| > 1),    tan(phi_last) = (-cs c2 + ss s2) / (ss c2 + cs s2).
+        // Nothing downstream decides anything by the last bits of a3 (b3 and the landing point follow from it by one subtraction
+        // and one division); what IS a decision — total reflection — is taken on the same quantity, |eta sin(theta_1)| > 1.
+        // ~48 instructions for atan2 + sin + asin + tan (~163).
+        const double rl = rsqrt_fast(fma(ldx, ldx, ldz * ldz));
+        const double cs = ldx * rl, ss = ldz * rl;
+        const double kq = rint(phi_l * 0.31830988618379067154);         // phi_l - kq pi in [-pi/2, pi/2]: cos(phi_l) has the sign (-1)^kq
+        const double cl = rtus_from_bits(rtus_bits(rsqrt_fast(fma(m, m, 1.0))) ^ ((uint64_t)(unsigned)(int)kq << 63));
+        const double sl = m * cl;
+        const double s2 = -k.eta12 * fma(cl, cs, sl * ss);
+        const double c2 = rtus_sqrt(fma(-s2, s2, 1.0));
+        const double num = fma(ss, s2, -(cs * c2));
+        a3 = rtus_div(num, cap_vertical(fma(ss, c2, cs * s2), num));
+#endif
     } else {
 #pragma clang fp contract(fast)
         // sin / cos of alpha_i = atan2(xi, zi) are xi/rho, zi/rho; then the refraction law as above.

@@ -13,7 +13,8 @@ more — a wrong polyline segment, branch or root is off by >= 1e-8 m on rays wh
 identical on every ray whose NaN status the oracle keeps under all nudges (a ray whose own NaN status flips with one ulp
 of its input is rounding-decided in the reference itself and is only counted); in a trace where U rays flip, U/4 further
 disagreements are tolerated (the degenerate continuum: offset 0, element on the axis, random grid with near-duplicate
-vertices — uniform grids, the reference's own, have U = 0 there).
+vertices — uniform grids, the reference's own, have U = 0 there); a trace that exceeds this is looked at again with 48 more
+noise patterns (the fourteen variants sample a degenerate trace's rounding-decided rays thinly) under the same rule.
 
     gpurun -- python scripts/fuzz_shoot.py [n_trials] [seed]
     python scripts/fuzz_shoot.py --selftest [...]   the same run, but every 97th finite ray of the GPU result is moved
@@ -43,6 +44,20 @@ def nudge(v, k):
 
 
 NOISE_MODES = [int(v) for v in np.random.default_rng(20260).integers(1, 2 ** 32, 10)]
+MORE_NOISE_MODES = [int(v) for v in np.random.default_rng(20261).integers(1, 2 ** 32, 48)]   # second look at a degenerate trace
+
+
+def nan_stable_under(modes, xa, za, zf, alpha, geoms):
+    """[G, T, n]: the ray keeps the NaN pattern of its eight outputs under each of these trigonometric noise patterns"""
+    base = np.isnan(cport.shoot_batch(xa, za, zf, alpha, geoms))
+    stable = np.ones(base.shape, dtype=bool)
+    try:
+        for mode in modes:
+            cport.set_trig_noise(mode)
+            stable &= np.isnan(cport.shoot_batch(xa, za, zf, alpha, geoms)) == base
+    finally:
+        cport.set_trig_noise(0)
+    return stable.all(axis=2)
 
 
 def oracle_with_spread(xa, za, zf, alpha, geoms):
@@ -97,6 +112,8 @@ def wrong_segment(got):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     selftest = "--selftest" in sys.argv
+    keep_going = "--keep-going" in sys.argv                    # count failing traces instead of stopping at the first (comparing builds)
+    n_fail = 0
     trials = int(args[0]) if len(args) > 0 else 150
     rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 12345)
     worst_ratio, worst_abs, rays, decided, noted, hard_total, t0 = 0.0, 0.0, 0, 0, 0, 0, time.time()
@@ -130,10 +147,23 @@ def main():
                 # near-duplicate vertices at offset 0 on the axis: every ray returns through its own vertex and the +-1e-9
                 # bounds check next to the duplicate is decided by rounding) holds more such rays than twelve nudges expose:
                 # the GPU may disagree on U/4 further rays there.  U = 0 (every other trace): no disagreement at all.
+                if hard.sum() > n_unstable // 4 and n_unstable > 0:
+                    # a degenerate trace (the oracle itself flips rays of it): the fourteen variants sample its rounding-decided
+                    # rays thinly.  Second look with 48 more noise patterns, same rule: disagreements only on rays the reference's
+                    # own arithmetic decides by rounding, plus a quarter of their number.
+                    more = nan_stable_under(MORE_NOISE_MODES, xa[t:t + 1], za[t:t + 1], zf, alpha, geoms[gi:gi + 1])[0, 0]
+                    ray_stable = ray_stable & more
+                    n_unstable = int((~ray_stable).sum())
+                    hard = mism & ray_stable
+                    print(f"note: degenerate trace, second look (62 noise patterns): trial {trial} geom={geoms[gi]} xa={xa[t]}: "
+                          f"{n_unstable} ray(s) flip in the oracle, {int(hard.sum())} disagreement(s) elsewhere")
                 if hard.sum() > n_unstable // 4:
                     bad = np.flatnonzero(hard)
                     print(f"NaN MASK MISMATCH trial {trial} n={n} geom={geoms[gi]} xa={xa[t]}: {hard.sum()} ray(s), first {bad[:5].tolist()}, "
                           f"whose NaN status the oracle keeps under every last-bit perturbation ({n_unstable} ray(s) of this trace do flip)")
+                    if keep_going:
+                        n_fail += 1
+                        continue
                     sys.exit(3 if selftest else 1)
                 decided += int((mism | ~ray_stable).sum())
                 hard_total += int(hard.sum())
@@ -146,6 +176,9 @@ def main():
                     k, ray = np.unravel_index(np.argmax(ratio), ratio.shape)
                     print(f"VALUE MISMATCH trial {trial} n={n} geom={geoms[gi]} xa={xa[t]}: {rtus.KEYS[k]}[{ray}] gpu {got[k, ray]!r} "
                           f"oracle {o[k, ray]!r} |d| {d[k, ray]:.3e} > 1e-12 + 16 x spread {sp[k, ray]:.3e}; ray (oracle): {o[:, ray].tolist()}")
+                    if keep_going:
+                        n_fail += 1
+                        continue
                     sys.exit(3 if selftest else 1)
                 worst_ratio = max(worst_ratio, float(ratio.max()))
                 worst_abs = max(worst_abs, float(d.max()))
@@ -159,6 +192,8 @@ def main():
         if trial % 25 == 24:
             print(f"trial {trial + 1}/{trials}: {rays} rays checked, worst |d| {worst_abs:.2e} m, worst |d| / allowed {worst_ratio:.3f}, "
                   f"{time.time() - t0:.0f} s", flush=True)
+    if keep_going:
+        print(f"--keep-going: {n_fail} failing trace(s) of {trials * 9}")
     if selftest:
         print("SELFTEST FAILED: the off-by-one segment index was not caught")
         sys.exit(1)
