@@ -10,7 +10,7 @@ OUT=$ROOT/variants; mkdir -p $OUT/obj_$NAME
 COMMON="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -fno-fast-math -fno-slp-vectorize"
 for f in rtus_shoot rtus_solve rtus_match rtus_fermat rtus_lens_fermat rtus_tfm rtus_capi; do
   fl=""
-  [ $f = rtus_shoot ] && fl="-ffp-contract=off"
+  [ $f = rtus_shoot ] && fl="-ffp-contract=off -mllvm -disable-machine-licm"
   [ $f = rtus_solve ] && fl="-ffp-contract=off -mllvm -disable-machine-licm"
   /opt/rocm/bin/hipcc $COMMON $fl $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
