@@ -338,8 +338,10 @@ int rtus_tt_lens_f32_multi_dev(const rtus_lens *lens, double alpha_lo, double al
  *   d_delays may be d_tt (in place).
  * rtus_tfm: total-focusing-method delay-and-sum over full-matrix-capture data,
  *   image[f] = sum over (tx, rx) of fmc[tx][rx][.] linearly interpolated at the sample position
- *   (tt_tx[tx][f] + tt_rx[rx][f] - t0) * fs.  Samples outside a record count as zero (records are expected to be
- *   windowed: zero at both ends); a pair without a ray path (NaN travel time) contributes nothing.
+ *   s = (tt_tx[tx][f] + tt_rx[rx][f] - t0) * fs, i.e. (1 - w) sample[i] + w sample[i + 1] with i = floor(s), w = s - i.  A
+ *   position before the record (s < 0) or at / past its end (s >= n_t) contributes nothing; in [n_t - 1, n_t) the missing
+ *   sample n_t counts as zero.  A pair without a ray path (NaN — or any non-finite or absurd travel time, |s| >= 1e8)
+ *   contributes nothing.  (oracle/tfm_numpy.py is the same definition.)
  *     fmc     [n_tx][n_rx][n_t] float32 A-scans, fs samples per second, first sample at time t0
  *     tt_tx   [n_tx][n_f], tt_rx [n_rx][n_f]  travel times (rtus_tt_layers* / rtus_tt_lens outputs; may be one table)
  *     image   [n_f] float32

@@ -116,24 +116,36 @@ __device__ __forceinline__ float tfm_tau(double t, double fs, double half_t0s)
     // travel time -> half of the pair's sample position (formed in fp64, rounded once: 1e-4 of a sample at 4096
     // samples); no path -> far outside every record (finite: the sum of two of them must not become NaN or wrap an
     // integer conversion)
+    // (... and so does every non-finite or absurd time: +inf would pass a NaN test and poison the pixel through floor(inf))
     const float v = (float)(t * fs - half_t0s);
-    return (t == t) ? v : -1.0e8f;
+    return fabsf(v) < 1.0e8f ? v : -1.0e8f;                  // NaN fails the compare
 }
 
 // Two neighbouring samples i, i + 1 of one A-scan (wave-uniform base) in one 8-byte load; an index outside the record
 // (negative, huge, the no-path sentinel) is dropped by the descriptor's range check and reads as zeros.
 #define RTUS_TFM_GROUP 16
+// Edges, as oracle/tfm_numpy.py defines them: a position in [n_t - 1, n_t) interpolates towards a zero sample n_t (the second
+// dword of the load is out of range by itself); a NEGATIVE position contributes nothing — index -1 must not wrap: its second
+// dword would sit at byte offset 2^32, which the range check sees as 0 — so negative indices (as unsigned: >= 2^31) are
+// clamped to one that is out of range with both dwords.  |i| stays below 2^30 (tfm_tau clamps to +-1e8 samples).
 __device__ __forceinline__ tfm_u32x2 tfm_load2(const float* rec, int n_t, int i)
 {
     const __amdgpu_buffer_rsrc_t q = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)n_t * 4u, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b64(q, (unsigned)i * 4u, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b64(q, min((unsigned)i, 0x3ffffff0u) * 4u, 0, 0);
 }
 
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
 {
     __shared__ float tau_rx[RTUS_TFM_RX_TILE][RTUS_BLOCK];           // 64 KB: 2 workgroups per CU; a 64-element receive
                                                                       // aperture is ONE tile: the transmit delays are read once
-    const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    // Workgroups go to the 8 XCDs round-robin, and each XCD has its own 4 MiB L2: with workgroup b on focal points
+    // [256 b, 256 b + 256) every XCD sees focal points from all over the image and pulls (its window of) the WHOLE FMC block
+    // through its L2.  XCD k takes a contiguous eighth of the focal points instead — neighbouring focal points share their
+    // sample windows — so the FMC block is fetched about once, not once per XCD (measured: profiles/traffic_r03.json).
+    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+    int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (nblk & 7) blk = blockIdx.x;                                   // (ragged grids keep the plain order)
+    const int f_raw = blk * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const size_t nf = (size_t)a.n_f;
@@ -149,8 +161,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tfm_kernel(TfmArgs a)
         // gather takes: 4 in flight 441 us, 8: 282 us, 16: 214 us (192 us with the whole receive aperture in one tile), 32 (two
         // transmit elements at once): 218 us — from 16 on
         // the vector-memory address path binds (64 scattered 8-byte requests per wave-instruction, ~27 cycles each per CU).
+        // one table for both legs and the whole receive aperture in this tile: the transmit delay IS a row of the tile
+        const bool tx_in_tile = a.tt_tx == a.tt_rx && a.n_tx == a.n_rx && a.n_rx <= RTUS_TFM_RX_TILE;
         for (int tx = 0; tx < a.n_tx; ++tx) {
-            const float tt = tfm_tau(a.tt_tx[(size_t)tx * nf + f], a.fs, a.half_t0s);
+            const float tt = tx_in_tile ? tau_rx[tx][threadIdx.x] : tfm_tau(a.tt_tx[(size_t)tx * nf + f], a.fs, a.half_t0s);
             const float* rec = a.fmc + ((size_t)tx * a.n_rx + r0) * (size_t)a.n_t;   // wave-uniform
             int r = 0;
             for (; r + RTUS_TFM_GROUP <= nr; r += RTUS_TFM_GROUP) {

@@ -100,3 +100,38 @@ def test_focal_delays_every_kernel_variant_is_exact(rtus):
         assert np.array_equal(dev_api.focal_delays_dev(t).cpu().numpy(), ref, equal_nan=True), (n_e, n_f)
         dev_api.focal_delays_dev(t, out=t)
         assert np.array_equal(t.cpu().numpy(), ref, equal_nan=True), ("in place", n_e, n_f)
+
+
+def test_tfm_record_edges_and_non_finite_times(rtus):
+    """UN-windowed random records, delays chosen to land just before the record (s in [-1, 0): nothing), on its last sample
+    (s in [n_t - 1, n_t): interpolates towards a zero sample n_t), exactly on samples 0 and n_t - 1, far outside, and
+    non-finite / absurd travel times — against oracle/tfm_numpy.py, which is the definition (include/rtus.h)."""
+    from oracle import tfm_numpy as T
+    rng = np.random.default_rng(5)
+    n_tx, n_rx, n_t, fs, t0 = 3, 5, 64, 1.0e6, 1.0e-6
+    fmc = rng.normal(0, 1, (n_tx, n_rx, n_t)).astype(np.float32)          # nothing zeroed at the ends
+    # (positions a rounding away from 0 or n_t are avoided: the kernel forms the position from two fp32 halves, the definition
+    # in fp64 — which side of the edge an exact 0.0 falls on is rounding)
+    pos = np.array([-1.0, -0.75, -0.25, -1e-3, 1e-3, 0.4, 1.0, n_t - 2.5, n_t - 1.0 + 1e-3, n_t - 0.6, n_t - 2e-3, n_t + 1e-3, n_t + 0.5,
+                    n_t + 40.0, -40.0, 3.0e7, -3.0e7, 1.0e9, 31.25])
+    n_f = pos.size
+    # sample position of pair (tx, rx) at focal point f: pos[f] + small per-pair shifts that keep every pair in the same case
+    sh_tx, sh_rx = np.array([0.0, 1e-4, 2e-4]), np.array([0.0, 3e-5, 6e-5, 9e-5, 1.2e-4])
+    tt_tx = (0.5 * pos[None, :] + sh_tx[:, None]) / fs + 0.5 * t0
+    tt_rx = (0.5 * pos[None, :] + sh_rx[:, None]) / fs + 0.5 * t0
+    img = rtus.tfm_image(fmc, fs, tt_tx, tt_rx, t0=t0)
+    ref = T.tfm(fmc, fs, t0, tt_tx, tt_rx)
+    assert np.isfinite(img).all()
+    assert np.max(np.abs(img - ref)) <= 1e-4 * max(1.0, np.max(np.abs(ref))), (img - ref)
+    before = pos < -4e-4                                                   # (the +<=3.2e-4 of shifts keeps them negative)
+    assert np.all(img[before & (pos > -2)] == 0.0) and np.all(img[pos >= n_t] == 0.0)
+    assert abs(img[list(pos).index(1e-3)]) > 0.1                            # ... and so does the first one just after 0
+    assert abs(img[list(pos).index(n_t - 0.6)]) > 0.1                       # the last sample does contribute there
+    # non-finite and absurd times: the pair is dropped, the pixel stays finite
+    bad = tt_tx.copy()
+    bad[1, :] = [np.inf, -np.inf, np.nan, 1e30, -1e30] + [np.inf] * (n_f - 5)
+    img_bad = rtus.tfm_image(fmc, fs, bad, tt_rx, t0=t0)
+    keep = np.array([0, 2])
+    ref_bad = T.tfm(fmc[keep], fs, t0, tt_tx[keep], tt_rx)
+    assert np.isfinite(img_bad).all()
+    assert np.max(np.abs(img_bad - ref_bad)) <= 1e-4 * max(1.0, np.max(np.abs(ref_bad)))
