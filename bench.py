@@ -630,7 +630,7 @@ def cpu_baseline(wl, gpu_table, torch):
 def cpu_ref_path():
     """CPU legs of the reference-parity path on this host: the NumPy port (the reference's own O(N^2) scan as
     2-D array ops, 1 core) and the C port (OpenMP) — forward trace only, reference sweep geometry."""
-    from oracle import cport, rt_numpy
+    from oracle import cport, rt_numpy, rt_numpy_loop
     R = ref_inputs("ref_sweep")
     d = float(R["za"][0])
     t0, k = time.perf_counter(), 0
@@ -640,11 +640,22 @@ def cpu_ref_path():
         k += 1
     np_rate = k * R["n"] / (time.perf_counter() - t0)
     t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 6.0:                       # the reference's loop structure: a Python loop over the rays
+        g = R["geoms"][k % len(R["geoms"])]
+        rt_numpy_loop.shoot(0.0, d, R["zf"], R["alpha"], g[0], g[1])
+        k += 1
+    loop_rate = k * R["n"] / (time.perf_counter() - t0)
+    t0, k = time.perf_counter(), 0
     while time.perf_counter() - t0 < 4.0:
         cport.shoot_batch(R["xa"], R["za"], R["zf"], R["alpha"], R["geoms"])
         k += 1
     c_rate = k * R["geoms"].shape[0] * R["n"] / (time.perf_counter() - t0)
-    return {"numpy_port_rays_per_s": round(np_rate, 1), "numpy_port_cores": 1,
+    return {"numpy_loop_port_rays_per_s": round(loop_rate, 1), "numpy_loop_port_cores": 1,
+            "numpy_loop_port_is": "oracle/rt_numpy_loop.py: the reference's own structure — vectorised prologue / epilogue around a Python "
+                                  "loop over the rays, ~10 NumPy calls on N-element arrays per ray (main_rt.py:384-393, 6-168), np.polyfit "
+                                  "replaced by the two-point line (half of the reference's time is polyfit: SURVEY section 3.1)",
+            "numpy_port_rays_per_s": round(np_rate, 1), "numpy_port_cores": 1,
+            "numpy_port_is": "oracle/rt_numpy.py: the same O(N^2) scan as 2-D array operations (no per-ray Python loop)",
             "c_port_rays_per_s": round(c_rate, 1), "c_port_cores": cport.num_threads(),
             "note": "forward trace at N = 905 (reference measured in SURVEY: 5.3 k rays/s on one core)"}
 

@@ -9,7 +9,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RTUS_LIB") or os.path.join(HERE, "librtus.so")   # RTUS_LIB: experiment builds only
+LIB_PATH = os.path.join(HERE, "librtus.so")
+if os.environ.get("RTUS_LIB"):           # experiment builds (scripts/build_variant.sh, interleaved A/B runs): never silently
+    LIB_PATH = os.environ["RTUS_LIB"]
+    print(f"[rtus] RTUS_LIB is set: loading {LIB_PATH} instead of the in-tree librtus.so", file=sys.stderr)
 CSRC = os.path.join(HERE, "csrc")
 
 _lib = None

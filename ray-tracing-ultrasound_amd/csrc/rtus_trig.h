@@ -10,6 +10,19 @@
 //
 // Plain C++ on purpose (fma / rint only): the same text compiles for the host, where tests/test_trig_kernels.py checks it
 // against 50-digit values without a GPU.
+//
+// The polynomial coefficients, the pi/2 splitting constants and the shape of the kernels (k_sin, k_cos, the medium branch of
+// rem_pio2, atan's aT[], asin's pS / qS) restate fdlibm as shipped in FreeBSD msun (k_sin.c, k_cos.c, e_rem_pio2.c, s_atan.c,
+// e_asin.c), whose files carry this notice:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <math.h>
 #include <stdint.h>

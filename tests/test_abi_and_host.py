@@ -129,3 +129,33 @@ assert len(paths) == 1, paths
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_kernel_resources_of_the_trace_kernels():
+    """What the build promises about the forward-trace and solve kernels, read from the code object's
+    metadata: no scratch in the forward trace, <= 80 / 96 VGPRs (6+ / 5 waves per SIMD), and the solve kernel's spills bounded."""
+    import subprocess
+    import tempfile
+    csrc = os.path.join(ROOT, "ray-tracing-ultrasound_amd", "csrc")
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize", "-ffp-contract=off", "-mllvm",
+             "-disable-machine-licm", "--cuda-device-only", "-S"]
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for f in ("rtus_shoot", "rtus_solve"):
+            out = os.path.join(td, f + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(csrc, f + ".hip"), "-o", out], check=True, capture_output=True, timeout=600)
+            name = None
+            for ln in open(out):
+                ln = ln.strip()
+                if ln.startswith(".name:"):
+                    name = ln.split()[1]
+                for key in (".vgpr_count:", ".vgpr_spill_count:", ".private_segment_fixed_size:"):
+                    if ln.startswith(key) and name:
+                        res.setdefault(name, {})[key] = int(ln.split()[1])
+    shoot = {k: v for k, v in res.items() if "rtus_shoot_kernel" in k}
+    solve = {k: v for k, v in res.items() if "rtus_solve_kernel" in k}
+    assert len(shoot) == 4 and len(solve) == 4
+    for k, v in shoot.items():
+        assert v[".private_segment_fixed_size:"] == 0 and v[".vgpr_spill_count:"] == 0 and v[".vgpr_count:"] <= 80, (k, v)
+    for k, v in solve.items():
+        assert v[".vgpr_count:"] <= 96 and v[".private_segment_fixed_size:"] <= 160, (k, v)

@@ -188,3 +188,14 @@ def test_planar_oracle_vs_50_digit_values():
             tt = fn(*a)
             assert np.array_equal(np.isnan(tt), ~m), name
             assert np.max(np.abs(tt - ref)[m] / ref[m]) < tol, (name, fn.__name__)
+
+
+def test_loop_structured_numpy_port_vs_reference():
+    """oracle/rt_numpy_loop.py keeps the reference's per-ray Python loop (main_rt.py:384-393); same goldens, same tolerances."""
+    from oracle import rt_numpy_loop
+    g = load_golden("compare_cfg.npz")
+    _check8(rt_numpy_loop.shoot(0.0, D_PLANE, g["zf"], g["alpha"], 0.037, 0.0038), g["out8"], "numpy-loop/compare")
+    e = load_golden("edge_cfg.npz")
+    for tag in ("q1nan", "tir", "off0", "offtx"):
+        r_o, off, x_tx = e[tag + "_cfg"]
+        _check8(rt_numpy_loop.shoot(x_tx, D_PLANE, np.full(905, D_PLANE), e["alpha"], r_o, off), e[tag], "numpy-loop/" + tag)
