@@ -1,7 +1,7 @@
 """Turns the rocprofv3 CSV output scripts/profile_round.sh leaves under gpurun_out/prof_<tag>/ into the small files
 committed under profiles/ (run in the build container after the gpurun call):
 
-    python scripts/profile_summarise.py r02
+    python scripts/profile_summarise.py r03
 """
 import collections
 import csv
@@ -10,7 +10,9 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+# the headline kernel of the round's bench line (r03: the tau-p accuracy tier of the planar solver)
+HEAD = {"r02": HEAD}.get(tag, "rtus_tt_layers_kernel<3, false, true, false>")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -79,11 +81,11 @@ bench = json.load(open(os.path.join(dst, f"{tag}_bench_k20.json")))
 
 # ---- kernel trace of the driver's command ------------------------------------------------------------------------
 kt = kernel_rows("kt", "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)")
-head = [r for r in kt if "rtus_tt_layers_kernel<3, false>" in r["kernel"]][0]
+head = [r for r in kt if HEAD in r["kernel"]][0]
 # the K timed launches alone: the headline kernel's dispatches in time order are W warm-up launches, the ~30 ms of untimed
 # graph replays (clock ramp), the K timed ones and one more inside `extra`; the driver's command has K = 20
 hd = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows_of("kt", "kernel_trace.csv")
-            if "rtus_tt_layers_kernel<3, false>" in r["Kernel_Name"])
+            if HEAD in r["Kernel_Name"])
 K = int(bench["steps"])
 timed = sorted(d for _, d in hd[-(K + 1):-1])
 if len(timed) == K:
@@ -92,8 +94,8 @@ if len(timed) == K:
 write_rows(os.path.join(dst, f"{tag}_bench_kernel_trace.csv"), kt)
 
 # ---- HBM traffic of the headline launch --------------------------------------------------------------------------
-wr, m1 = counters(["wr"], "rtus_tt_layers_kernel<3, false>")
-rd, m2 = counters(["rd"], "rtus_tt_layers_kernel<3, false>")
+wr, m1 = counters(["wr"], HEAD)
+rd, m2 = counters(["rd"], HEAD)
 write_counters(os.path.join(dst, f"{tag}_pmc_WRITE_SIZE_cfg3.csv"), wr, m1)
 write_counters(os.path.join(dst, f"{tag}_pmc_FETCH_SIZE_cfg3.csv"), rd, m2)
 hk = list(wr)[0]
@@ -118,7 +120,7 @@ for k in cw:
 json.dump(traffic, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 
 # ---- SQ counters: headline kernel and the other table kernels ------------------------------------------------------
-sq, meta = counters(["sq", "sq2", "sq3"], "rtus_tt_layers_kernel<3, false>")
+sq, meta = counters(["sq", "sq2", "sq3"], HEAD)
 write_counters(os.path.join(dst, f"{tag}_pmc_sq_cfg3.csv"), sq, meta)
 valu = {}
 c = sq[hk]
@@ -175,10 +177,82 @@ for mode, name in ((0, "compat"), (1, "fast")):
               f"SMEM/wave {cs.get('SQ_INSTS_SMEM', 0) / cs['SQ_WAVES']:.0f}")
 write_rows(os.path.join(dst, f"{tag}_consumers_kernel_rows.csv"), kernel_rows("kt_cons", "scripts/run_consumers_once.py"))
 
-# ---- instruction issue costs ----------------------------------------------------------------------------------------
-with open(os.path.join(dst, f"{tag}_ubench_issue.txt"), "w") as fh:
-    for n in ("ubench_issue", "ubench_issue2", "ubench_issue3", "ubench_issue4"):
-        fh.write(f"==== scripts/{n}.hip ====\n" + open(os.path.join(src, n + ".txt")).read() + "\n")
+# ---- instruction issue costs (round 2's tables; later rounds re-use them) ------------------------------------------------
+if os.path.exists(os.path.join(src, "ubench_issue.txt")):
+    with open(os.path.join(dst, f"{tag}_ubench_issue.txt"), "w") as fh:
+        for n in ("ubench_issue", "ubench_issue2", "ubench_issue3", "ubench_issue4"):
+            fh.write(f"==== scripts/{n}.hip ====\n" + open(os.path.join(src, n + ".txt")).read() + "\n")
+
+# ---- issue-bound objects of the other kernels bench.py prints a roofline_valu for -----------------------------------------
+def clock_of(c):
+    return c["GRBM_GUI_ACTIVE"] / 8.0 / c["_duration_ns:GRBM_GUI_ACTIVE"] if "GRBM_GUI_ACTIVE" in c else 2.1
+
+
+# the multi-GPU headline's kernel: configs[3] shard of 8 (128 rows x 1024^2 targets, fp32)
+tl, ml = counters(["sq_cfg4_lens_f32", "sq_cfg4_lens_f32_b", "sq_cfg4_lens_f32_c"], "rtus_tt_lens_kernel")
+if tl:
+    lk = [k for k in tl if "float" in k][0]
+    c = tl[lk]
+    ws = 128 * 1048576 / 64.0
+    f32 = c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
+    tr = c.get("SQ_INSTS_VALU_TRANS_F32", 0)
+    cv = c.get("SQ_INSTS_VALU_CVT", 0)
+    f64 = c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
+    oth = c["SQ_INSTS_VALU"] - f32 - tr - cv - f64
+    # fp32 FMA-class with VGPR operands 2.3 cycles, transcendental 8.2, cvt / fp64 4.2, the rest (compares, selects, bit ops) ~3.3;
+    # the scalar ALU issues beside the VALU for free up to one scalar per vector instruction (profiles/r02_ubench_issue.txt)
+    issue = f32 * 2.3 + tr * 8.2 + (cv + f64) * 4.2 + oth * 3.3
+    valu["cfg4_lens_f32"] = {
+        "kernel": lk, "insts_valu_per_solve": round(c["SQ_INSTS_VALU"] / ws, 2), "insts_salu_per_solve": round(c["SQ_INSTS_SALU"] / ws, 2),
+        "insts_valu_per_solve_by_class": {"fp32_fma_mul_add": round(f32 / ws, 2), "trans_f32": round(tr / ws, 2), "cvt": round(cv / ws, 2),
+                                          "fp64": round(f64 / ws, 2), "other": round(oth / ws, 2)},
+        "issue_cycles_per_wave_solve": round(issue / ws, 1), "clock_ghz": round(clock_of(c), 3),
+        "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+        "workload_of_the_counters": "128 tx rows x 1024 x 1024 targets (one of eight shards of BASELINE configs[3])",
+        "issue_cycles_how": "instruction classes x issue cycles per wave-instruction of profiles/r02_ubench_issue.txt"}
+
+# forward trace, reference geometry 1024 tx x 8192 rays
+for mode, key in ((0, "ref_scale"), (1, "ref_scale_fastmath")):
+    t, m = counters([f"sq_shoot{mode}", f"sq_shoot{mode}b"], "rtus_shoot_kernel")
+    for k, c in t.items():
+        w = c["SQ_WAVES"]
+        fl = 2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
+        valu[key] = {"kernel": k, "waves": int(w), "insts_valu_per_wave": round(c["SQ_INSTS_VALU"] / w, 1),
+                     "insts_salu_per_wave": round(c["SQ_INSTS_SALU"] / w, 1), "insts_smem_per_wave": round(c.get("SQ_INSTS_SMEM", 0) / w, 1),
+                     "fp64_arith_insts_per_wave": round((c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) +
+                                                         c.get("SQ_INSTS_VALU_MUL_F64", 0)) / w, 1),
+                     "issue_cycles_per_pass": round(c["SQ_INSTS_VALU"] * 4.2, 0), "fp64_flop_per_pass": round(fl * 64, 0),
+                     "clock_ghz": round(clock_of(c), 3),
+                     "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+                     "issue_cycles_how": "4.2 issue cycles per VALU wave-instruction (fp64 and everything beside it in this kernel: "
+                                         "compares, selects, bit operations; profiles/r02_ubench_issue.txt)"}
+
+# root-finding solve: both kernels of a pass
+solve_rows = []
+for size in ("sweep", "scale"):
+    for mode, suffix in (("compat", ""), ("fast", "_fastmath")):
+        t, m = counters([f"sq_solve_{size}_{mode}", f"sq_solve_{size}_{mode}b"], "rtus_s")
+        if not t:
+            continue
+        write_counters(os.path.join(dst, f"{tag}_pmc_solve_{size}_{mode}.csv"), t, m)
+        solve_rows += kernel_rows(f"kt_solve_{size}_{mode}", f"scripts/run_solve_once.py {size} {mode}")
+        per = {}
+        tot_valu = fl = 0.0
+        clk = 2.1
+        for k, c in t.items():
+            short = "grid_trace" if "shoot" in k else "refine"
+            w = c["SQ_WAVES"]
+            per[short] = {"kernel": k, "waves": int(w), "insts_valu_per_wave": round(c["SQ_INSTS_VALU"] / w, 1),
+                          "insts_salu_per_wave": round(c["SQ_INSTS_SALU"] / w, 1), "insts_smem_per_wave": round(c.get("SQ_INSTS_SMEM", 0) / w, 1),
+                          "insts_valu": int(c["SQ_INSTS_VALU"]), "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4)}
+            tot_valu += c["SQ_INSTS_VALU"]
+            fl += (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)) * 64
+            clk = clock_of(c) if "GRBM_GUI_ACTIVE" in c else clk
+        valu[f"solve_{size}{suffix}"] = {"kernels": per, "issue_cycles_per_pass": round(tot_valu * 4.2, 0), "fp64_flop_per_pass": round(fl, 0),
+                                         "clock_ghz": round(clk, 3),
+                                         "issue_cycles_how": "VALU wave-instructions of both kernels x 4.2 issue cycles, spread over 1024 SIMDs"}
+write_rows(os.path.join(dst, f"{tag}_solve_kernel_rows.csv"), solve_rows)
+json.dump(valu, open(os.path.join(dst, f"valu_{tag}.json"), "w"), indent=1)
 
 print("headline kernel:", hk, "| kernel-trace avg ns", head["avg_ns"], "median", head["median_ns"], "calls", head["calls"])
 print("bench.py (un-profiled, K=20): value", bench["value"], "ms/step", bench["ms_per_step"], "avg_launch_ms", bench["roofline"]["avg_launch_ms"],
