@@ -51,6 +51,7 @@ extern "C" int rtus_solve_stamps_read(unsigned long long* out)
 #define RTUS_SOLVE_WAVES 4
 #endif
 #define RTUS_SOLVE_TPB (RTUS_SOLVE_WAVES * 64)
+#define RTUS_RESCUE_MAX 21          // brackets of one wave that can borrow two finished lanes each
 #ifndef RTUS_SOLVE_MIN_WAVES
 #define RTUS_SOLVE_MIN_WAVES 5
 #endif
@@ -88,13 +89,21 @@ __device__ __forceinline__ double solve_iqi(double xa, double fa, double xb, dou
     return xa + fa * q * (db * fc * (fc - fa) - dc * fb * (fb - fa));
 }
 
-template <bool FAST, bool MASKS>
+// EPB (mask mode): element lanes per workgroup.  256 = all four waves; 128 = two waves of elements, four waves of brackets: with
+// about one bracket per element the list then fits ONE trip of the four waves even where elements have two (a list of 260
+// brackets on 256 lanes costs its workgroup a second trip for four of them — in a launch of a few hundred waves that trip is
+// the kernel's critical path).  The launcher takes 128 for launches that leave SIMDs idle anyway.
+template <bool FAST, bool MASKS, int EPB = RTUS_SOLVE_TPB>
 __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(RTUS_SOLVE_MIN_WAVES, 8))) void rtus_solve_kernel(SolveArgs q)
 {
     __shared__ unsigned items[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];        // (slot << 2 | k) is implied by position: see below
     __shared__ int item_r[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
     __shared__ double res_t[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS], res_a[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
     __shared__ int wave_tot[RTUS_SOLVE_WAVES];
+#ifndef RTUS_SOLVE_NO_RESCUE
+    __shared__ double resc_in[RTUS_SOLVE_WAVES][RTUS_RESCUE_MAX][6];      // xa, za, r_outer, pipe_offset, candidate, delta
+    __shared__ double resc_out[RTUS_SOLVE_WAVES][RTUS_RESCUE_MAX][2][2];  // [below / above the candidate] = landing x, travel time
+#endif
     const ShootArgs& a = q.s;
     const LensK& k = a.k;
     const int n = a.n;
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     int e;
     bool live, task_live;
     if (MASKS) {
-        const long long flat = (long long)blockIdx.x * RTUS_SOLVE_TPB + threadIdx.x;
-        live = flat < q.n_tasks;                                       // n_tasks = rows * n_rx here
+        const long long flat = (long long)blockIdx.x * EPB + threadIdx.x;
+        live = flat < q.n_tasks && (int)threadIdx.x < EPB;             // n_tasks = rows * n_rx here
         const long long fl = live ? flat : q.n_tasks - 1;
         t_row = fl / q.n_rx;
         e = (int)(fl - t_row * q.n_rx);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         long long row;
         int ie;
         if (MASKS) {
-            const long long fl = (long long)blockIdx.x * RTUS_SOLVE_TPB + owner;
+            const long long fl = (long long)blockIdx.x * EPB + owner;
             row = fl / q.n_rx;
             ie = (int)(fl - row * q.n_rx);
         } else {
@@ -275,7 +284,44 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         for (int it = 0; it < 64; ++it) {
             if (!__any(!done)) break;
             STAMP(3 + min(it, 9));
-            const double ac = cand;                                      // a finished lane re-traces its last point: same bits, ignored
+            // Stragglers.  99.3 % of the brackets are done after two evaluations, but a wave runs until its slowest lane is, and
+            // in a small launch (the reference's sweep: 214 waves on 1024 SIMDs) the kernel lasts as long as its slowest wave:
+            // four evaluations of ~12 us for a handful of brackets.  From the third evaluation on, an unfinished bracket borrows
+            // two FINISHED lanes of its wave: they trace its candidate c moved by -delta / +delta (delta = half the step that led
+            // to c), and the bracket finishes from three fresh points around its root — inverse quadratic interpolation for
+            // alpha, the parabola through the three travel times for T, error third order in delta — instead of iterating on.
+            bool helper = false, rescued = false;
+            int hj = 0, hs = 0, rj = 0;
+            double ac = cand;                                            // a finished lane re-traces its last point: same bits, ignored
+#ifndef RTUS_SOLVE_NO_RESCUE
+            double delta = 0.0;
+            if (it >= 2) {                                               // wave-uniform
+                const lanemask U = __ballot(!done), Dm = __ballot(done);
+                const int nu = __popcll(U);
+                if (nu <= RTUS_RESCUE_MAX && __popcll(Dm) >= 2 * nu) {
+                    const int j = __builtin_amdgcn_mbcnt_hi((unsigned)(U >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)U, 0));
+                    const int h = __builtin_amdgcn_mbcnt_hi((unsigned)(Dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Dm, 0));
+                    delta = fmin(0.5 * fabs(cand - xp), 0.999 * fmin(cand - xlo, xhi - cand));
+                    rescued = !done && delta > 0.0;
+                    rj = j;
+                    if (!done) {
+                        double* r = resc_in[wv][j];
+                        r[0] = in.xa; r[1] = in.za; r[2] = in.r_outer; r[3] = in.off; r[4] = cand; r[5] = rescued ? delta : 0.0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (done && h < 2 * nu) {
+                        const double* r = resc_in[wv][h >> 1];
+                        if (r[5] > 0.0) {
+                            helper = true; hj = h >> 1; hs = h & 1;
+                            in.xa = r[0]; in.za = r[1]; in.r_outer = r[2]; in.off = r[3];
+                            ac = hs ? r[4] + r[5] : r[4] - r[5];
+                        }
+                    }
+                }
+            }
+#endif
             double sn, cs, px, pz, dz, dx;
             rtus_sincos(ac, sn, cs);                                     // |alpha| < 8: the bounded-range kernels
             lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
@@ -290,6 +336,30 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
             const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
             const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
             const double T = ((t1 + t2) + t3) + t4;
+#ifndef RTUS_SOLVE_NO_RESCUE
+            if (it >= 2) {                                               // wave-uniform
+                if (helper) { resc_out[wv][hj][hs][0] = o.x_in; resc_out[wv][hj][hs][1] = T; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (rescued && isfinite(fc)) {
+                    const double fm = resc_out[wv][rj][0][0] - xr, fq = resc_out[wv][rj][1][0] - xr;
+                    const double Tm = resc_out[wv][rj][0][1], Tq = resc_out[wv][rj][1][1];
+                    // the root inside the three points (a sign change between the outer two) and x_land monotone over them
+                    if ((fm < 0.0) != (fq < 0.0) && (fq - fc) * (fc - fm) > 0.0 && fc != 0.0) {
+                        const double xr3 = solve_iqi(ac, fc, ac - delta, fm, ac + delta, fq);
+                        const double u = (xr3 - ac) * solve_rcp(delta);  // in (-1, 1)
+                        if (fabs(u) < 1.0) {
+                            ++nev;
+                            done = true;
+                            f_fin = 0.0;                                 // bracketed between fresh points 2 delta apart: a root
+                            x_fin = xr3;
+                            T_fin = T + 0.5 * u * ((Tq - Tm) + u * ((Tq - T) - (T - Tm)));
+                        }
+                    } else if (fc == 0.0) { ++nev; done = true; f_fin = 0.0; x_fin = ac; T_fin = T; }
+                }
+            }
+#endif
             if (!done) {
                 ++nev;
                 if (!isfinite(fc)) { dead = true; done = true; }         // the branch ends inside the bracket
@@ -399,13 +469,17 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     q.chunks = (n_rx + 63) / 64;
     q.n_tasks = masks ? (long long)n_geom * n_tx * n_rx : (long long)n_geom * n_tx * q.chunks;
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
-    const long long blocks = masks ? (q.n_tasks + RTUS_SOLVE_TPB - 1) / RTUS_SOLVE_TPB : (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
+    // mask mode, launches that leave SIMDs idle anyway (fewer than two waves of elements per SIMD): 128 element lanes per workgroup
+    const bool half = masks && q.n_tasks <= 2LL * 1024 * 64;
+    const long long epb = half ? RTUS_SOLVE_TPB / 2 : RTUS_SOLVE_TPB;
+    const long long blocks = masks ? (q.n_tasks + epb - 1) / epb : (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks);
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
-#define RTUS_SOLVE_LAUNCH(F, M) hipLaunchKernelGGL((rtus_solve_kernel<F, M>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q)
-    if (masks) { if (fast) RTUS_SOLVE_LAUNCH(true, true); else RTUS_SOLVE_LAUNCH(false, true); }
-    else { if (fast) RTUS_SOLVE_LAUNCH(true, false); else RTUS_SOLVE_LAUNCH(false, false); }
+#define RTUS_SOLVE_LAUNCH(F, M, E) hipLaunchKernelGGL((rtus_solve_kernel<F, M, E>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q)
+    if (half) { if (fast) RTUS_SOLVE_LAUNCH(true, true, RTUS_SOLVE_TPB / 2); else RTUS_SOLVE_LAUNCH(false, true, RTUS_SOLVE_TPB / 2); }
+    else if (masks) { if (fast) RTUS_SOLVE_LAUNCH(true, true, RTUS_SOLVE_TPB); else RTUS_SOLVE_LAUNCH(false, true, RTUS_SOLVE_TPB); }
+    else { if (fast) RTUS_SOLVE_LAUNCH(true, false, RTUS_SOLVE_TPB); else RTUS_SOLVE_LAUNCH(false, false, RTUS_SOLVE_TPB); }
 #undef RTUS_SOLVE_LAUNCH
     return hipGetLastError();
 }
