@@ -12,7 +12,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 # the headline kernel of the round's bench line (r03: the tau-p accuracy tier of the planar solver)
-HEAD = {"r02": HEAD}.get(tag, "rtus_tt_layers_kernel<3, false, true, false>")
+HEAD = {"r02": "rtus_tt_layers_kernel<3, false>"}.get(tag, "rtus_tt_layers_kernel<3, false, true, false>")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -185,7 +185,11 @@ if os.path.exists(os.path.join(src, "ubench_issue.txt")):
 
 # ---- issue-bound objects of the other kernels bench.py prints a roofline_valu for -----------------------------------------
 def clock_of(c):
-    return c["GRBM_GUI_ACTIVE"] / 8.0 / c["_duration_ns:GRBM_GUI_ACTIVE"] if "GRBM_GUI_ACTIVE" in c else 2.1
+    """effective shader clock of the counter pass; dispatches shorter than ~0.1 ms read far too high (the counter keeps running
+    between a short dispatch's end and its read-out): the nominal 2.1 GHz there"""
+    if "GRBM_GUI_ACTIVE" not in c or c["_duration_ns:GRBM_GUI_ACTIVE"] < 1.0e5:
+        return 2.1
+    return c["GRBM_GUI_ACTIVE"] / 8.0 / c["_duration_ns:GRBM_GUI_ACTIVE"]
 
 
 # the multi-GPU headline's kernel: configs[3] shard of 8 (128 rows x 1024^2 targets, fp32)
@@ -193,7 +197,7 @@ tl, ml = counters(["sq_cfg4_lens_f32", "sq_cfg4_lens_f32_b", "sq_cfg4_lens_f32_c
 if tl:
     lk = [k for k in tl if "float" in k][0]
     c = tl[lk]
-    ws = 128 * 1048576 / 64.0
+    ws = 1024 * 1048576 / 64.0                      # bench.py --workload cfg4_lens_f32 on ONE GPU solves the whole 1024-row table
     f32 = c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
     tr = c.get("SQ_INSTS_VALU_TRANS_F32", 0)
     cv = c.get("SQ_INSTS_VALU_CVT", 0)
@@ -208,7 +212,7 @@ if tl:
                                           "fp64": round(f64 / ws, 2), "other": round(oth / ws, 2)},
         "issue_cycles_per_wave_solve": round(issue / ws, 1), "clock_ghz": round(clock_of(c), 3),
         "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
-        "workload_of_the_counters": "128 tx rows x 1024 x 1024 targets (one of eight shards of BASELINE configs[3])",
+        "workload_of_the_counters": "the whole BASELINE configs[3] table on one GPU: 1024 tx rows x 1024 x 1024 targets",
         "issue_cycles_how": "instruction classes x issue cycles per wave-instruction of profiles/r02_ubench_issue.txt"}
 
 # forward trace, reference geometry 1024 tx x 8192 rays
@@ -247,7 +251,7 @@ for size in ("sweep", "scale"):
                           "insts_valu": int(c["SQ_INSTS_VALU"]), "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4)}
             tot_valu += c["SQ_INSTS_VALU"]
             fl += (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)) * 64
-            clk = clock_of(c) if "GRBM_GUI_ACTIVE" in c else clk
+            clk = clock_of(c) if "shoot" in k else clk                  # the longer of the two dispatches
         valu[f"solve_{size}{suffix}"] = {"kernels": per, "issue_cycles_per_pass": round(tot_valu * 4.2, 0), "fp64_flop_per_pass": round(fl, 0),
                                          "clock_ghz": round(clk, 3),
                                          "issue_cycles_how": "VALU wave-instructions of both kernels x 4.2 issue cycles, spread over 1024 SIMDs"}
