@@ -1,0 +1,64 @@
+"""GPU: (1) the NumPy API first, the torch-tensor API afterwards, in a FRESH process without conftest's torch pre-import — the
+process must hold one HIP runtime and the device entry must work on torch's pointers and stream;
+(2) RTUS_POLYLINE_READY: a call that keeps the polyline of the previous call on the same workspace gives the same bits."""
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import D_PLANE, ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+assert "torch" not in sys.modules
+import numpy as np, rtus
+xe = (np.arange(24) - 11.5) * 0.6e-3
+xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 40), np.linspace(0.025, 0.065, 30))
+host = rtus.travel_time_layers([0.02], [2330.0, 1483.0], xe, np.zeros(24), xs.ravel(), zs.ravel())     # loads librtus.so
+assert "torch" not in sys.modules
+import torch                                                                                            # ... and only now torch
+from importlib import import_module
+dev = import_module("ray-tracing-ultrasound_amd.device")
+t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+with torch.cuda.stream(torch.cuda.Stream()):
+    got = dev.tt_layers_dev([0.02], [2330.0, 1483.0], t(xe), t(np.zeros(24)), t(xs.ravel()), t(zs.ravel()))
+torch.cuda.synchronize()
+assert np.array_equal(got.cpu().numpy(), host)
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+assert len(libs) == 1, libs
+print("ok", libs[0])
+""" % ROOT
+
+
+def test_numpy_api_first_then_torch_api_in_a_fresh_process():
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_polyline_ready_keeps_the_bits(rtus):
+    import torch
+    from importlib import import_module
+    dev = import_module("ray-tracing-ultrasound_amd.device")
+    s = load_golden("sweep_cfg.npz")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    alpha, xe = t(s["alpha"]), t(s["x_elem"])
+    n = s["alpha"].size
+    plan = dev.SolvePlan(4, 2, n, 65, params=rtus.Params(), all_roots=True)
+    xa, za = t([0.0, 0.004]), t([D_PLANE, D_PLANE])
+    a = plan.run(t(s["geoms"][[3, 50, 120, 200]]), xa, za, alpha, xe)
+    first = {k: v.clone() for k, v in a.items()}
+    b = plan.run(t(s["geoms"][[7, 51, 121, 201]]), xa, za, alpha, xe, polyline_ready=True)      # other geometries, same grid
+    kept = {k: v.clone() for k, v in b.items()}
+    c = plan.run(t(s["geoms"][[7, 51, 121, 201]]), xa, za, alpha, xe)
+    for k in kept:
+        assert torch.equal(kept[k].view(torch.uint8), c[k].view(torch.uint8)), k
+    assert not torch.equal(first["tt"].nan_to_num(), kept["tt"].nan_to_num())
+    sp = dev.ShootPlan(2, 2, n, want=("out8",), params=rtus.Params())
+    zf = t(np.full(n, D_PLANE))
+    o1 = sp.run(t(s["geoms"][[3, 50]]), xa, za, alpha, zf)["out8"].clone()
+    o2 = sp.run(t(s["geoms"][[3, 50]]), xa, za, alpha, zf, polyline_ready=True)["out8"]
+    assert torch.equal(o1.view(torch.uint8), o2.view(torch.uint8))
