@@ -3,15 +3,24 @@
 some inside deeper layers), random targets (some above their element -> NaN, offsets up to 100x the depth), sizes that
 exercise every workgroup shape (n_e 1..300, n_f 1..5000).  Checks NaN masks and |dt| <= 1e-16 s + 2e-11 t.
 
-    gpurun -- python scripts/fuzz_layers.py [n_trials] [seed]
+    gpurun -- python scripts/fuzz_layers.py [n_trials] [seed] [--taup]
+--taup: the tau-p accuracy tier through the device-side sorted entry (rtus_tt_layers_sorted_dev), |dt| <= 1e-16 s + 1e-10 t.
 """
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rtus
 from oracle import cport
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
+TAUP = "--taup" in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+trials = int(args[0]) if len(args) > 0 else 200
+rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 4242)
+REL = 1e-10 if TAUP else 2e-11
+if TAUP:
+    import torch
+    from importlib import import_module
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
 worst_rel, worst_abs, solves, t0 = 0.0, 0.0, 0, time.time()
 for trial in range(trials):
     n_if = int(rng.integers(0, 9))
@@ -32,7 +41,10 @@ for trial in range(trials):
         ze = np.repeat(rng.uniform(-0.003, 0.5 * depth, (n_e + 7) // 8), 8)[:n_e]          # depth changes every 8 elements
     xf = rng.uniform(-0.06, 0.06, n_f) * (100.0 if rng.random() < 0.1 else 1.0)
     zf = rng.uniform(-0.002, depth + 0.03, n_f)
-    tt = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)
+    if TAUP:
+        tt = dev_api.tt_layers_sorted_dev(z_if, c, t64(xe), t64(ze), t64(xf), t64(zf), taup=True).cpu().numpy()
+    else:
+        tt = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)
     ref = cport.tt_layers(z_if, c, xe, ze, xf, zf)
     if not np.array_equal(np.isnan(tt), np.isnan(ref)):
         bad = np.argwhere(np.isnan(tt) != np.isnan(ref))
@@ -43,8 +55,8 @@ for trial in range(trials):
         err = np.abs(tt - ref)[m]
         worst_abs = max(worst_abs, float(err.max()))
         worst_rel = max(worst_rel, float((err / ref[m]).max()))
-        if np.any(err > 1e-16 + 2e-11 * ref[m]):
-            i = np.argmax(err / (1e-16 + 2e-11 * ref[m]))
+        if np.any(err > 1e-16 + REL * ref[m]):
+            i = np.argmax(err / (1e-16 + REL * ref[m]))
             e, f = np.argwhere(m)[i]
             print(f"VALUE MISMATCH trial {trial} n_if={n_if} c={c.tolist()} z_if={z_if.tolist()} elem ({xe[e]}, {ze[e]}) target ({xf[f]}, {zf[f]}): "
                   f"gpu {tt[e, f]!r} oracle {ref[e, f]!r}")
@@ -52,4 +64,4 @@ for trial in range(trials):
     solves += int(m.sum())
     if trial % 50 == 49:
         print(f"trial {trial + 1}/{trials}: {solves} solves, worst rel {worst_rel:.2e} abs {worst_abs:.2e} s, {time.time() - t0:.0f} s", flush=True)
-print(f"OK: {trials} trials, {solves} solves, worst rel {worst_rel:.2e}, worst abs {worst_abs:.2e} s")
+print(f"OK{' (tau-p tier, sorted entry)' if TAUP else ''}: {trials} trials, {solves} solves, worst rel {worst_rel:.2e}, worst abs {worst_abs:.2e} s")
