@@ -323,13 +323,33 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
     // --- reflection on the pipe (main_rt.py:367-376); tangent ignores pipe_offset --
     // RTUS_TRUE_PIPE_TANGENT (not the reference): tangent of the circle where it actually is
     const double xt = (a.flags & RTUS_TRUE_PIPE_TANGENT) ? xq - off : xq;
-    const double slope = FAST ? -xt * rsqrt_fast(r_outer * r_outer - xt * xt)
-                              : rtus_div(-xt, rtus_sqrt(r_outer * r_outer - xt * xt));   // :237-238
-    double m, phi_l = 0.0, lx_u = 0.0, lz_u = 0.0;
+    double m, lx_u = 0.0, lz_u = 0.0;
+    unsigned cl_neg = 0;                            // compat: bit 31 = cos(phi_l) < 0 (with m, that is phi_l's unit vector: the exit refraction's input)
+    const double slope = FAST ? -xt * rsqrt_fast(r_outer * r_outer - xt * xt) : 0.0;
     if (!FAST) {
-        const double phi_sl = rtus_atan(slope);                        // :287
-        phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));  // :289-291
+#ifdef RTUS_ANGLE_FORM_REFLECTION                            // comparison builds: the reference's angle chain, operation for operation
+        const double slope_c = rtus_div(-xt, rtus_sqrt(r_outer * r_outer - xt * xt));   // :237-238
+        const double phi_sl = rtus_atan(slope_c);                      // :287
+        const double phi_l = phi_sl - RTUS_PI_2 - (phi_pq - (phi_sl + RTUS_PI_2));      // :289-291
         m = rtus_tan(phi_l);                                           // :375
+        cl_neg = (unsigned)(int)rint(phi_l * 0.31830988618379067154) << 31;   // phi_l - k pi in [-pi/2, pi/2]: cos(phi_l) has the sign (-1)^k
+#else
+        // :237-238, 287-291, 375  tan(phi_l) with phi_l = 2 atan(s) - phi_pq, s = -x_t / sqrt(r^2 - x_t^2), without the angles: with
+        // s = p / q (p = -x_t, q = sqrt(r^2 - x_t^2) >= 0) and a = tan(phi_pq),
+        //     cos(phi_l) ~ sigma ((q^2 - p^2) + 2 p q a) = sigma D,      sin(phi_l) ~ sigma (2 p q - (q^2 - p^2) a) = sigma N
+        // up to a positive factor, sigma = the sign of cos(phi_pq) — and phi_pq IS formed as an angle above.  m = N / D needs no
+        // division for the slope and no atan / tan (~28 instructions for ~107); a tangent hit (q = 0: the reference's slope is
+        // infinite, atan gives +-pi/2) comes out as m = -a by itself; |x_t| > r is NaN through the square root, as in
+        // the reference.  The crossing search sees m a few ulps from tan(fl(phi_l)) — the rounding of another math library.
+        const double q2 = r_outer * r_outer - xt * xt;
+        const double pq2 = -2.0 * (xt * rtus_sqrt(q2));                // 2 p q
+        const double c2q = q2 - xt * xt;                               // q^2 - p^2
+        const double Np = fma(-c2q, a_pq, pq2);
+        const double Dp = cap_vertical(fma(pq2, a_pq, c2q), Np);
+        m = rtus_div(Np, Dp);
+        // cos(phi_pq) has the sign (-1)^k, k = rint(phi_pq / pi); cos(phi_l) that sign times the sign of D
+        cl_neg = ((unsigned)(int)rint(phi_pq * 0.31830988618379067154) << 31) ^ ((unsigned)__double2hiint(Dp) & 0x80000000u);
+#endif
     } else {
 #pragma clang fp contract(fast)
         // phi_l = 2 phi_sl - phi_pq with tan(phi_sl) = slope: rotate u by 2 phi_sl and mirror.
@@ -493,12 +513,12 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         rtus_div2(xi, zi, rho, si, ci);
         lens_eval_sc(k, si, ci, lx, lz, ldz, ldx);         // analytic tangent at the chord point's polar angle
 #ifdef RTUS_ANGLE_FORM_EXIT                                 // comparison builds: the reference's angle chain for the exit refraction too
-        const double phi_last = refract_angle(phi_l, rtus_atan2(ldz, ldx), k.eta12);   // :398
+        const double cl_ = rtus_from_bits(0x3ff0000000000000ull ^ ((uint64_t)cl_neg << 32));
+        const double phi_last = refract_angle(atan2(m * cl_, cl_), rtus_atan2(ldz, ldx), k.eta12);   // :398 (phi_l back from its slope and the sign of its cosine)
         a3 = rtus_tan(phi_last);                                       // :401
 #else
         // :398-401  tan(phi_s - pi/2 + asin(eta sin(phi_l - (phi_s + pi/2)))), phi_s = atan2(dz, dx), without forming an angle:
-        // with the unit tangent (cs, ss) = (dx, dz) / |.| and the unit vector of phi_l, (cl, sl) = +-(1, m) / sqrt(1 + m^2) — the
-        // sign is that of cos(phi_l), and phi_l IS known as an angle —
+        // with the unit tangent (cs, ss) = (dx, dz) / |.| and the unit vector (cl, sl) of phi_l from the reflection above —
         //   sin(theta_1) = -cos(phi_l - phi_s) = -(cl cs + sl ss),   s2 = eta sin(theta_1),   c2 = sqrt(1 - s2^2)  (NaN beyond
         //   the critical angle: the reference's asin of |x| > 1),    tan(phi_last) = (-cs c2 + ss s2) / (ss c2 + cs s2).
         // Nothing downstream decides anything by the last bits of a3 (b3 and the landing point follow from it by one subtraction
@@ -506,8 +526,7 @@ __device__ __forceinline__ void trace_ray(const ShootArgs& a, const RayIn& in, R
         // ~48 instructions for atan2 + sin + asin + tan (~163).
         const double rl = rsqrt_fast(fma(ldx, ldx, ldz * ldz));
         const double cs = ldx * rl, ss = ldz * rl;
-        const double kq = rint(phi_l * 0.31830988618379067154);         // phi_l - kq pi in [-pi/2, pi/2]: cos(phi_l) has the sign (-1)^kq
-        const double cl = rtus_from_bits(rtus_bits(rsqrt_fast(fma(m, m, 1.0))) ^ ((uint64_t)(unsigned)(int)kq << 63));
+        const double cl = rtus_from_bits(rtus_bits(rsqrt_fast(fma(m, m, 1.0))) ^ ((uint64_t)cl_neg << 32));   // (cl, sl) = +-(1, m) / sqrt(1 + m^2)
         const double sl = m * cl;
         const double s2 = -k.eta12 * fma(cl, cs, sl * ss);
         const double c2 = rtus_sqrt(fma(-s2, s2, 1.0));
