@@ -44,10 +44,9 @@ def _run(lib, path):
 
 
 def test_assembly_walk_and_cxx_walk_give_the_same_bits(tmp_path):
-    variant = os.path.join(ROOT, "variants", "librtus_walkcxx.so")
-    if not os.path.exists(variant):                                  # a box that did not get the prebuilt variant: build it here
-        subprocess.run(["bash", os.path.join(ROOT, "scripts", "build_variant.sh"), "walkcxx", "-DRTUS_WALK_CXX"], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    variant = entry.build_walk_cxx_variant()                         # rebuilt here if missing or made from other sources than this tree's
     a = _run(None, str(tmp_path / "asm.npz"))
     b = _run(variant, str(tmp_path / "cxx.npz"))
     assert set(a.files) == set(b.files) and len(a.files) >= 9
