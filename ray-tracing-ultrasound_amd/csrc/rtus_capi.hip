@@ -100,7 +100,8 @@ struct Session {                       // one host-buffer call on one device
     int dev_index = -1;
     // the session ends with its stream drained whatever happened in between (an early return after flush() must not leave
     // copies in flight while the next call re-uses the page-locked buffer)
-    ~Session() { if (a && a->stream) (void)hipStreamSynchronize(a->stream); }
+    bool drained = false;              // finish() came back clean: nothing in flight
+    ~Session() { if (a && a->stream && !drained) (void)hipStreamSynchronize(a->stream); }
     int open(int device, size_t dev_bytes, int slot = 0)
     {
         int n = 0;
@@ -168,6 +169,7 @@ struct Session {                       // one host-buffer call on one device
                 if (e != hipSuccess) return e;
                 e = hipStreamSynchronize(a->stream);
                 if (e != hipSuccess) return e;
+                drained = true;
                 for (int i = 0; i < n_down; ++i) memcpy(down[i].host, stage + (down[i].off - lo), down[i].bytes);
                 return hipSuccess;
             }
@@ -176,7 +178,9 @@ struct Session {                       // one host-buffer call on one device
                 if (e != hipSuccess) return e;
             }
         }
-        return hipStreamSynchronize(a->stream);
+        const hipError_t e = hipStreamSynchronize(a->stream);
+        drained = e == hipSuccess;
+        return e;
     }
 };
 }   // namespace
