@@ -2,7 +2,7 @@
 // reference's grid scan + tolerance matcher, main_rt.py:479-501).  Its own translation unit because it is compiled with
 // -mllvm -disable-machine-licm (Makefile): the iteration is a LOOP around trace_ray, and the machine-level loop-invariant
 // code motion hoists the ~60 64-bit literals and scalar table loads of the trigonometric kernels out of it — 242 VGPRs
-// and 110 spilled SGPRs; without the hoisting 123 VGPRs and nothing in scratch.
+// and 110 spilled SGPRs; without the hoisting 123 - 131 VGPRs and (almost) nothing in scratch.
 #include "rtus_trace.h"
 
 // ---- pulse-echo root-finding solve ------------------------------------------------------------
@@ -52,8 +52,11 @@ extern "C" int rtus_solve_stamps_read(unsigned long long* out)
 #endif
 #define RTUS_SOLVE_TPB (RTUS_SOLVE_WAVES * 64)
 #define RTUS_RESCUE_MAX 21          // brackets of one wave that can borrow two finished lanes each
+// Waves per SIMD the register allocation aims at.  5 (96 VGPRs, what VERDICT r02 asked for) costs ~70 spilled registers since
+// the straggler hand-over came in; 4 (128 VGPRs, 2 spilled) measured faster at both sizes: 73.6 -> 71.5 us per sweep-sized pass,
+// 841 -> 822 us at scale (vector form 707 -> 663 us); 3 is slower again at scale.
 #ifndef RTUS_SOLVE_MIN_WAVES
-#define RTUS_SOLVE_MIN_WAVES 5
+#define RTUS_SOLVE_MIN_WAVES 4
 #endif
 struct SolveArgs {
     ShootArgs s;                        // lens, geometry, tx, polyline + boxes, flags

@@ -133,7 +133,8 @@ assert len(paths) == 1, paths
 
 def test_kernel_resources_of_the_trace_kernels():
     """What the build promises about the forward-trace and solve kernels, read from the code object's
-    metadata: no scratch in the forward trace, <= 80 / 96 VGPRs (6+ / 5 waves per SIMD), and the solve kernel's spills bounded."""
+    metadata: no scratch in the forward trace, <= 80 VGPRs there (6+ waves per SIMD), <= 128 in the solve kernel (4 waves) with at
+    most a few spilled registers."""
     import subprocess
     import tempfile
     csrc = os.path.join(ROOT, "ray-tracing-ultrasound_amd", "csrc")
@@ -158,4 +159,4 @@ def test_kernel_resources_of_the_trace_kernels():
     for k, v in shoot.items():
         assert v[".private_segment_fixed_size:"] == 0 and v[".vgpr_spill_count:"] == 0 and v[".vgpr_count:"] <= 80, (k, v)
     for k, v in solve.items():
-        assert v[".vgpr_count:"] <= 96 and v[".private_segment_fixed_size:"] <= 160, (k, v)
+        assert v[".vgpr_count:"] <= 128 and v[".private_segment_fixed_size:"] <= 32, (k, v)
