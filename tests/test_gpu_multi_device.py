@@ -81,3 +81,49 @@ def test_multi_dev_variant_one_device_no_exchange(rtus):
     assert st == 0
     torch.cuda.synchronize()
     assert np.array_equal(tt[:40].cpu().numpy(), rtus.travel_time_layers(z_if, c, xe, ze, xf, zf))
+
+
+def test_multi_dev_variant_two_shards_left_sharded(rtus):
+    """rtus_tt_layers_multi_dev / rtus_tt_lens_f32_multi_dev with two entries on the one GPU of this pool and gather = 0 (an RCCL
+    communicator needs distinct devices): each entry solves its row block IN PLACE inside its own copy of the padded table, on its
+    own stream; the two blocks together are the one-device table, bit for bit."""
+    import torch
+    z_if, c, xe, ze, xf, zf = _planar(150, 144)
+    t = lambda a, dt=np.float64: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device="cuda")
+    L = rtus.lib()
+    per = int(L.rtus_shard_rows(150, xf.size, 8, 2))
+    assert per % L.rtus_table_rows_per_block(150, xf.size, 8) == 0 and per < 150
+    txe, tze, txf, tzf = t(xe), t(ze), t(xf), t(zf)
+    tabs = [torch.full((2 * per, xf.size), -1.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    arr = lambda ts: (C.c_void_p * 2)(*[x.data_ptr() for x in ts])
+    zi, cc = np.asarray(z_if, dtype=np.float64), np.asarray(c, dtype=np.float64)
+    st = L.rtus_tt_layers_multi_dev(zi.ctypes.data, cc.ctypes.data, 2, arr([txe, txe]), arr([tze, tze]), 150, arr([txf, txf]), arr([tzf, tzf]),
+                                    xf.size, arr(tabs), (C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)(*[s.cuda_stream for s in streams]), 0)
+    assert st == 0
+    torch.cuda.synchronize()
+    one = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)
+    a, b = tabs[0].cpu().numpy(), tabs[1].cpu().numpy()
+    assert np.array_equal(a[:per], one[:per]) and np.array_equal(b[per:150], one[per:])
+    assert np.all(a[per:] == -1.0) and np.all(b[:per] == -1.0) and np.all(b[150:] == -1.0)        # nothing outside a shard's own rows is touched
+    # gather = 1 with the same device listed twice cannot build a communicator: reported, not crashed
+    st = L.rtus_tt_layers_multi_dev(zi.ctypes.data, cc.ctypes.data, 2, arr([txe, txe]), arr([tze, tze]), 150, arr([txf, txf]), arr([tzf, tzf]),
+                                    xf.size, arr(tabs), (C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)(*[s.cuda_stream for s in streams]), 1)
+    torch.cuda.synchronize()
+    assert st in (0, -5)                                             # RTUS_ERR_UNSUPPORTED (no librccl / duplicate devices) or a working RCCL
+    # the fp32 lens table the same way
+    n_e = 150
+    xl, zl = np.meshgrid(np.linspace(-0.004, 0.004, 256), np.linspace(0.03, 0.07, 128))
+    xe32, ze32 = t((np.arange(n_e) - 74.5) * 0.3e-4, np.float32), t(np.full(n_e, D_PLANE), np.float32)
+    xf32, zf32 = t(xl.ravel(), np.float32), t(zl.ravel(), np.float32)
+    per32 = int(L.rtus_shard_rows(n_e, xl.size, 4, 2))
+    tabs32 = [torch.zeros((2 * per32, xl.size), dtype=torch.float32, device="cuda") for _ in range(2)]
+    lens = rtus.Params().lens()
+    st = L.rtus_tt_lens_f32_multi_dev(C.byref(lens), -rtus.ALPHA_MAX, rtus.ALPHA_MAX, arr([xe32, xe32]), arr([ze32, ze32]), n_e, arr([xf32, xf32]),
+                                      arr([zf32, zf32]), xl.size, arr(tabs32), (C.c_int * 2)(0, 0), 2,
+                                      (C.c_void_p * 2)(*[s.cuda_stream for s in streams]), 0)
+    assert st == 0
+    torch.cuda.synchronize()
+    one32 = rtus.travel_time_lens(xe32.cpu().numpy(), ze32.cpu().numpy(), xl.ravel(), zl.ravel(), params=rtus.Params(), dtype=np.float32)
+    assert np.array_equal(tabs32[0][:per32].cpu().numpy(), one32[:per32]) and np.array_equal(tabs32[1][per32:n_e].cpu().numpy(), one32[per32:])
