@@ -368,19 +368,17 @@ def main(argv=None):
     else:
         R = ref_inputs(wl)
         G, T, N = R["geoms"].shape[0], R["xa"].size, R["n"]
-        plan = dev_api.ShootPlan(G, T, N, want=("tof", "land_x"), params=rtus.Params(), device=dev)
+        # one body of the reference's parameter loop for every row: forward trace + element matcher in ONE kernel (rtus_sweep_dev)
+        plan = dev_api.SweepPlan(G, T, N, R["x_rx"].size, want=("tof", "land_x"), params=rtus.Params(), atol=1e-6, rtol=1e-5, device=dev)
         geoms, xa, za, alpha, zf = t64(R["geoms"]), t64(R["xa"]), t64(R["za"]), t64(R["alpha"]), t64(R["zf"])
         x_rx = t64(R["x_rx"])
-        mout = None
         units_per_step = G * T * N
         total_units_per_step = units_per_step * world
         alg_bytes = units_per_step * 16 + N * 16       # tof + land_x written per ray; alpha, z_f read once
-        kernel = "rtus_shoot_kernel<false>"
+        kernel = "rtus_shoot_kernel<false, false, true>"
 
         def step(s):
-            nonlocal mout
-            o = plan.run(geoms, xa, za, alpha, zf)
-            mout = dev_api.match_dev(o["land_x"].view(G * T, N), o["tof"].view(G * T, N), x_rx, 1e-6, 1e-5, out=mout)
+            plan.run(geoms, xa, za, alpha, zf, x_rx)
 
         def drain():
             pass
@@ -710,7 +708,27 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
             one_pass()
         dt = _best_ms(torch, one_pass, 20 if kind == "ref_sweep" else 5) * 1e-3
         rays = G * T * N
-        entry = {"Mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4), "rays_per_pass": rays}
+        entry = {"Mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_pass": round(dt * 1e3, 4), "rays_per_pass": rays,
+                 "what": "rtus_shoot_dev + rtus_match_dev (two calls, the per-ray arrays go through HBM), eager launches"}
+        # the same work through the fused entry (rtus_sweep_dev: the matcher inside the trace kernel), with and without the per-ray arrays
+        for tag, want in (("fused", ("tof", "land_x")), ("fused_hits_only", ())):
+            fplan = dev_api.SweepPlan(G, T, N, R["x_rx"].size, want=want, params=rtus.Params(), fast=fast, atol=1e-6, rtol=1e-5)
+            fpass = lambda: fplan.run(*a, x_rx)
+            for _ in range(3):
+                fpass()
+            torch.cuda.synchronize()
+            if tag == "fused":
+                same = all(torch.equal(fplan.out[k].view(G * T, -1), box[0][i]) for i, k in enumerate(("first_ray", "hit", "tof_hit")))
+            tg = Timed(torch, lambda s: fpass(), 20 if kind == "ref_sweep" else 5)
+            dtg, msg = tg.run(lambda: None)
+            entry[tag] = {"ms_per_pass_graph": round(msg, 5), "Mrays_per_s": round(rays / (msg * 1e-3) / 1e6, 2),
+                          "ms_per_pass_eager": round(_best_ms(torch, fpass, 20 if kind == "ref_sweep" else 5), 4)}
+            if tag == "fused":
+                entry[tag]["equals_two_calls"] = bool(same)
+            del fplan, tg
+        tg = Timed(torch, lambda s: one_pass(), 20 if kind == "ref_sweep" else 5)
+        entry["ms_per_pass_graph"] = round(tg.run(lambda: None)[1], 5)
+        del tg
         if kind == "ref_scale":
             # roofline of the forward-trace kernel alone (HIP events around the trace, matcher excluded)
             ms = _event_ms(torch, lambda: plan.run(*a), 5)

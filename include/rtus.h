@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUS_VERSION 102 /* 0.1.2: rtus_solve_workspace_bytes takes n_rx */
+#define RTUS_VERSION 103 /* 0.1.2: rtus_solve_workspace_bytes takes n_rx */
 
 typedef enum rtus_status {
     RTUS_OK = 0,
@@ -193,6 +193,39 @@ int rtus_ray_hits_dev(const double *d_land_x, int n_batch, int n_rays, const dou
 
 int rtus_ray_hits(const double *land_x, int n_batch, int n_rays, const double *x_rx, int n_rx,
                   double atol, double rtol, uint8_t *ray_hit, int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused sweep — one body of the reference's parameter loop, main_rt.py:464-501: shoot_rays for every
+ * (geometry, transmit element) row with the element matcher on its landing points inside the trace
+ * kernel (the matcher runs on the landing points while they are still in registers; a small second
+ * kernel turns the winners into first_ray / hit / tof_hit).  Results are bit-identical to rtus_shoot*
+ * followed by rtus_match* on its land_x / tof outputs.
+ *
+ *   geoms, x_a, z_a, alpha, z_f, flags   as rtus_shoot*
+ *   x_rx [n_rx], atol, rtol               as rtus_match*   (any n_rx; rows * (n_rx rounded up to 64) < 2^31)
+ *   first_ray / hit / tof_hit [n_geom*n_tx][n_rx]   as rtus_match*   (hit, tof_hit nullable)
+ *   tof, land_x [n_geom*n_tx][n_rays]     nullable: the per-ray arrays, stored only when asked for
+ *   workspace  rtus_sweep_workspace_bytes(n_rays, n_geom, n_tx, n_rx) bytes, 64-byte aligned.
+ *              RTUS_POLYLINE_READY here means: the previous call on this workspace was rtus_sweep_dev
+ *              with the same alpha, n_rays, n_geom, n_tx and n_rx (the lens polyline is kept AND the
+ *              matcher's scratch was left idle by that call).
+ * ---------------------------------------------------------------------------------------- */
+size_t rtus_sweep_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx);
+
+int rtus_sweep_dev(const rtus_lens *lens, const double *d_geoms, int n_geom,
+                   const double *d_x_a, const double *d_z_a, int n_tx,
+                   const double *d_alpha, const double *d_z_f, int n_rays,
+                   const double *d_x_rx, int n_rx, double atol, double rtol,
+                   int32_t *d_first_ray, uint8_t *d_hit, double *d_tof_hit,
+                   double *d_tof, double *d_land_x,
+                   void *d_workspace, size_t workspace_bytes, unsigned flags, void *stream);
+
+int rtus_sweep(const rtus_lens *lens, const double *geoms, int n_geom,
+               const double *x_a, const double *z_a, int n_tx,
+               const double *alpha, const double *z_f, int n_rays,
+               const double *x_rx, int n_rx, double atol, double rtol,
+               int32_t *first_ray, uint8_t *hit, double *tof_hit,
+               double *tof, double *land_x, unsigned flags, int device);
 
 /* ------------------------------------------------------------------------------------------
  * Element x focal-point Fermat travel times through horizontal layers (BASELINE configs 2, 3, 5).

@@ -7,7 +7,7 @@ module at the repo root) or ``importlib.import_module("ray-tracing-ultrasound_am
 from ._lib import EXPORTS, LIB_PATH, Lens, RtusError, build, lib  # noqa: F401
 from .api import (ALPHA_MAX, KEYS, Params, configure, match_elements, ray_hits,  # noqa: F401
                   reference_elements, shoot_batch, shoot_rays, travel_time_layers, travel_time_lens,
-                  fmc_table_layers, solve_travel_times, focal_delays, tfm_image)
+                  fmc_table_layers, solve_travel_times, focal_delays, tfm_image, sweep_batch)
 
-__all__ = ["shoot_rays", "shoot_batch", "match_elements", "ray_hits", "travel_time_layers", "travel_time_lens", "fmc_table_layers", "solve_travel_times", "focal_delays", "tfm_image", "Params",
+__all__ = ["shoot_rays", "shoot_batch", "sweep_batch", "match_elements", "ray_hits", "travel_time_layers", "travel_time_lens", "fmc_table_layers", "solve_travel_times", "focal_delays", "tfm_image", "Params",
            "configure", "reference_elements", "ALPHA_MAX", "KEYS", "build", "lib", "RtusError"]

@@ -87,6 +87,12 @@ def lib():
     L.rtus_shoot.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, dp, dp, dp, vp, C.c_uint, ip]
     L.rtus_match_dev.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, vp]
     L.rtus_match.argtypes = [dp, dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, ip]
+    L.rtus_sweep_workspace_bytes.argtypes = [ip, ip, ip, ip]
+    L.rtus_sweep_workspace_bytes.restype = C.c_size_t
+    L.rtus_sweep_dev.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, dp, dp, vp, C.c_size_t,
+                                 C.c_uint, vp]
+    L.rtus_sweep.argtypes = [LP, dp, ip, dp, dp, ip, dp, dp, ip, dp, ip, C.c_double, C.c_double, vp, vp, dp, dp, dp, C.c_uint, ip]
+    L.rtus_sweep_dev.restype = L.rtus_sweep.restype = ip
     L.rtus_ray_hits_dev.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, vp]
     L.rtus_ray_hits.argtypes = [dp, ip, ip, dp, ip, C.c_double, C.c_double, vp, ip]
     L.rtus_tt_layers_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, vp]
@@ -153,4 +159,4 @@ EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_
            "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm",
            "rtus_tt_layers_sort_workspace_bytes", "rtus_tt_layers_sorted_dev", "rtus_table_rows_per_block", "rtus_shard_rows", "rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev",
            "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi", "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev",
-           "rtus_tt_lens_f32_multi_dev")
+           "rtus_tt_lens_f32_multi_dev", "rtus_sweep_workspace_bytes", "rtus_sweep_dev", "rtus_sweep")

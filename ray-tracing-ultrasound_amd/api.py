@@ -201,6 +201,46 @@ def match_elements(land_x, tof, x_rx, atol=1e-6, rtol=1e-5, *, device=0):
     return (hit.astype(bool).reshape(lead + (E,)), tof_hit.reshape(lead + (E,)), first.reshape(lead + (E,)))
 
 
+def sweep_batch(x_a, z_a, z_f, alpha, x_rx, geoms=None, *, atol=1e-6, rtol=1e-5, params: Params = None, want=(), fast=False,
+                true_tangent=False, analytic_lens=False, device=0):
+    """One body of the reference's parameter loop (main_rt.py:464-501) for n_geom geometries x n_tx transmit points in ONE kernel:
+    ``shoot_batch`` and ``match_elements`` fused — the matcher runs on the landing points while they are in registers.
+
+    Returns {"hit" bool[G,T,E], "tof_hit" f64[G,T,E] (0.0 where no ray hits), "first_ray" int32[G,T,E] (-1 where none)} plus the
+    per-ray arrays named in ``want`` ("tof", "land_x": [G,T,N]).  Bit-identical to the two calls it replaces.
+    """
+    p = _resolve(params)
+    x_a, z_a = _f64(x_a, "x_a"), _f64(z_a, "z_a")
+    alpha, z_f, x_rx = _f64(alpha, "alpha"), _f64(z_f, "z_f"), _f64(x_rx, "x_rx")
+    if x_a.shape != z_a.shape:
+        raise ValueError("x_a and z_a must have the same length")        # main_rt.py:28-29
+    if alpha.shape != z_f.shape:
+        raise ValueError("alpha and z_f must have the same length")
+    if alpha.size < 2:
+        raise ValueError("Curve needs at least two points.")             # main_rt.py:26-27
+    geoms = (np.asarray([[p.r_outer, p.pipe_offset]], dtype=np.float64) if geoms is None
+             else _f64(geoms, "geoms", 2))
+    if geoms.shape[1] != 2:
+        raise ValueError("geoms must be [n_geom, 2] = (r_outer, pipe_offset)")
+    G, T, N, E = geoms.shape[0], x_a.size, alpha.size, x_rx.size
+    bufs = dict(tof=None, land_x=None)
+    for w in want:
+        if w not in bufs:
+            raise ValueError(f"unknown output {w!r}")
+        bufs[w] = np.empty((G, T, N), dtype=np.float64)
+    first = np.empty((G, T, E), dtype=np.int32)
+    hit = np.empty((G, T, E), dtype=np.uint8)
+    tof_hit = np.empty((G, T, E), dtype=np.float64)
+    lens = p.lens()
+    st = _lib.lib().rtus_sweep(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), _ptr(z_f), N, _ptr(x_rx), E,
+                               float(atol), float(rtol), _ptr(first), _ptr(hit), _ptr(tof_hit), _ptr(bufs["tof"]), _ptr(bufs["land_x"]),
+                               _flags(fast, true_tangent, analytic_lens), int(device))
+    _lib.check(st, "rtus_sweep")
+    out = {"hit": hit.astype(bool), "tof_hit": tof_hit, "first_ray": first}
+    out.update({w: bufs[w] for w in want})
+    return out
+
+
 def ray_hits(land_x, x_rx, atol=1e-4, rtol=1e-5, *, device=0):
     """Per ray: does any element match (main_compare.py:518-521)."""
     land_x = np.ascontiguousarray(land_x, dtype=np.float64)

@@ -24,6 +24,11 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
                              const double* z_a, int n_tx, const double* alpha, int n, const double* x_rx, int n_rx,
                              double z_land, double* tt, double* alpha_root, double* tt_all,
                              double* alpha_all, uint8_t* n_roots, void* ws, unsigned flags, hipStream_t s);
+size_t rtus_sweep_ws_bytes(int n, int n_geom, int n_tx, int n_rx);
+hipError_t rtus_launch_sweep(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a, const double* z_a, int n_tx,
+                             const double* alpha, const double* z_f, int n, const double* x_rx, int n_rx, double atol, double rtol,
+                             int32_t* first_ray, uint8_t* hit, double* tof_hit, double* tof, double* land_x, void* ws, unsigned flags,
+                             hipStream_t s);
 hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batch, int n, const double* x_rx,
                              int n_rx, double atol, double rtol, int32_t* first_ray,
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s);
@@ -488,6 +493,76 @@ int rtus_ray_hits(const double* land_x, int n_batch, int n_rays, const double* x
     HIP_TRY(S.flush());
     LAUNCH_TRY(rtus_launch_match(lx, nullptr, n_batch, n_rays, rx, n_rx, atol, rtol, nullptr, nullptr, nullptr, rh, S.a->stream));
     S.download(ray_hit, rh, rn);
+    HIP_TRY(S.finish());
+    return RTUS_OK;
+}
+
+// ---------------------------------------------------------------------------- fused sweep (forward trace + matcher)
+size_t rtus_sweep_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx)
+{
+    return (n_rays > 0 && n_geom > 0 && n_tx > 0 && n_rx > 0) ? rtus_sweep_ws_bytes(n_rays, n_geom, n_tx, n_rx) : 0;
+}
+
+static int check_sweep(const rtus_lens* lens, const void* geoms, int n_geom, const void* x_a, const void* z_a, int n_tx,
+                       const void* alpha, const void* z_f, int n_rays, const void* x_rx, int n_rx, double atol, double rtol,
+                       const void* first_ray, unsigned flags)
+{
+    int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f, n_rays);
+    if (st) return st;
+    if (!x_rx || !first_ray || n_rx <= 0 || !(atol >= 0) || !(rtol >= 0)) return RTUS_ERR_INVALID_ARG;
+    if (flags & ~RTUS_SHOOT_KNOWN_FLAGS) return RTUS_ERR_INVALID_ARG;
+    const long long rows = (long long)n_geom * n_tx, rx_pad = ((long long)n_rx + 63) & ~63LL;
+    if (rows * rx_pad + rows > 0x7fffffffLL) return RTUS_ERR_UNSUPPORTED;
+    return RTUS_OK;
+}
+
+int rtus_sweep_dev(const rtus_lens* lens, const double* d_geoms, int n_geom, const double* d_x_a, const double* d_z_a, int n_tx,
+                   const double* d_alpha, const double* d_z_f, int n_rays, const double* d_x_rx, int n_rx, double atol, double rtol,
+                   int32_t* d_first_ray, uint8_t* d_hit, double* d_tof_hit, double* d_tof, double* d_land_x, void* d_workspace,
+                   size_t workspace_bytes, unsigned flags, void* stream)
+{
+    int st = check_sweep(lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_x_rx, n_rx, atol, rtol, d_first_ray, flags);
+    if (st) return st;
+    if (!d_workspace || ((uintptr_t)d_workspace & 63) || workspace_bytes < rtus_sweep_ws_bytes(n_rays, n_geom, n_tx, n_rx)) return RTUS_ERR_WORKSPACE;
+    LAUNCH_TRY(rtus_launch_sweep(*lens, d_geoms, n_geom, d_x_a, d_z_a, n_tx, d_alpha, d_z_f, n_rays, d_x_rx, n_rx, atol, rtol, d_first_ray,
+                              d_hit, d_tof_hit, d_tof, d_land_x, d_workspace, flags, (hipStream_t)stream));
+    return RTUS_OK;
+}
+
+int rtus_sweep(const rtus_lens* lens, const double* geoms, int n_geom, const double* x_a, const double* z_a, int n_tx,
+               const double* alpha, const double* z_f, int n_rays, const double* x_rx, int n_rx, double atol, double rtol,
+               int32_t* first_ray, uint8_t* hit, double* tof_hit, double* tof, double* land_x, unsigned flags, int device)
+{
+    int st = check_sweep(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, z_f, n_rays, x_rx, n_rx, atol, rtol, first_ray, flags);
+    if (st) return st;
+    const size_t rows = (size_t)n_geom * n_tx, n = (size_t)n_rays, rn = rows * n, re = rows * (size_t)n_rx;
+    const size_t wsb = rtus_sweep_ws_bytes(n_rays, n_geom, n_tx, n_rx);
+    const size_t need = al256(16 * (size_t)n_geom) + 2 * al256(8 * (size_t)n_tx) + 2 * al256(8 * n) + al256(8 * (size_t)n_rx) + al256(wsb) +
+                        al256(4 * re) + (hit ? al256(re) : 0) + (tof_hit ? al256(8 * re) : 0) + (tof ? al256(8 * rn) : 0) +
+                        (land_x ? al256(8 * rn) : 0);
+    Session S;
+    if ((st = S.open(device, need))) return st;
+    double *g, *xa, *za, *al, *zf, *rx;
+    S.upload(g, geoms, 2 * (size_t)n_geom);
+    S.upload(xa, x_a, n_tx);
+    S.upload(za, z_a, n_tx);
+    S.upload(al, alpha, n);
+    S.upload(zf, z_f, n);
+    S.upload(rx, x_rx, n_rx);
+    void* ws = S.take<char>(wsb);
+    int32_t* fr = S.take<int32_t>(re);
+    uint8_t* hb = hit ? S.take<uint8_t>(re) : nullptr;
+    double* th = tof_hit ? S.take<double>(re) : nullptr;
+    double* tt = tof ? S.take<double>(rn) : nullptr;
+    double* lx = land_x ? S.take<double>(rn) : nullptr;
+    HIP_TRY(S.flush());
+    LAUNCH_TRY(rtus_launch_sweep(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, rx, n_rx, atol, rtol, fr, hb, th, tt, lx, ws,
+                              flags & ~RTUS_POLYLINE_READY, S.a->stream));
+    S.download(first_ray, fr, re);
+    S.download(hit, hb, re);
+    S.download(tof_hit, th, re);
+    S.download(tof, tt, rn);
+    S.download(land_x, lx, rn);
     HIP_TRY(S.finish());
     return RTUS_OK;
 }

@@ -7,7 +7,7 @@
 // bit-identical to the sequential scan); a second tiny kernel turns the winner into hit / tof.
 #include "rtus_device.h"
 
-#define RTUS_NO_RAY 0x7f7f7f7f   // hipMemsetAsync(0x7f) sentinel; larger than any ray index
+#define RTUS_NO_RAY 0x7f7f7f7f   // hipMemsetAsync(0x7f) sentinel; larger than any ray index (also rtus_trace.h: the fused sweep)
 
 struct MatchArgs {
     const double* __restrict__ land_x;  // [n_batch][n]
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
     for (int e = threadIdx.x; e < a.n_rx; e += RTUS_BLOCK) {
         const double xe = a.x_rx[e];
         sx[e] = xe;
-        stol[e] = a.atol + a.rtol * fabs(xe);      // np.isclose: atol + rtol*|b|, b = elem_x
+        stol[e] = __dadd_rn(a.atol, __dmul_rn(a.rtol, fabs(xe)));      // np.isclose: atol + rtol*|b|, b = elem_x (two roundings, as NumPy)
         asc = asc && isfinite(xe) && (e == 0 || a.x_rx[e - 1] <= xe);
         amax = fmax(amax, fabs(xe));
     }

@@ -84,9 +84,11 @@ __global__ __launch_bounds__(RTUS_CURVE_TPB) void rtus_curve_kernel(LensK k, con
                                                                      double2* __restrict__ tan_u,
                                                                      double4* __restrict__ node0,
                                                                      double4* __restrict__ node1,
-                                                                     double4* __restrict__ node2)
+                                                                     double4* __restrict__ node2, int32_t* __restrict__ m_init, int m_init_n)
 {
     __shared__ double red[4][RTUS_CURVE_TPB / 64];
+    // (the fused sweep's matcher scratch rides along, as in rtus_geom1_kernel)
+    for (int i = blockIdx.x * RTUS_CURVE_TPB + threadIdx.x; i < m_init_n; i += gridDim.x * RTUS_CURVE_TPB) m_init[i] = RTUS_NO_RAY;
     curve_part(k, alpha, n, curve, phi_s, tan_u, node0, node1, node2, blockIdx.x, threadIdx.x, red);
 }
 
@@ -148,9 +150,12 @@ __global__ void rtus_tree_kernel(const double4* __restrict__ node0, const double
 __global__ __launch_bounds__(RTUS_GEOM1_TPB) void rtus_geom1_kernel(LensK k, const double* __restrict__ alpha, int n,
                                                                      double2* __restrict__ curve, double* __restrict__ phi_s,
                                                                      double2* __restrict__ tan_u, double4* node0, double4* node1,
-                                                                     double4* node2, int n0, int n1, int n2, TreeNode* tree)
+                                                                     double4* node2, int n0, int n1, int n2, TreeNode* tree,
+                                                                     int32_t* m_init, int m_init_n)
 {
     __shared__ double red[2][4][RTUS_CURVE_TPB / 64];
+    // the fused sweep's matcher scratch ("no ray yet"), when it is small enough to ride along here
+    for (int i = threadIdx.x; i < m_init_n; i += RTUS_GEOM1_TPB) m_init[i] = RTUS_NO_RAY;
     const int part = threadIdx.x / RTUS_CURVE_TPB;
     curve_part(k, alpha, n, curve, phi_s, tan_u, node0, node1, node2, part, threadIdx.x % RTUS_CURVE_TPB, red[part]);
     __threadfence();                               // the boxes are read back from global memory (no __restrict__ on them here)
@@ -170,7 +175,10 @@ __global__ __launch_bounds__(RTUS_GEOM1_TPB) void rtus_geom1_kernel(LensK k, con
 // landing interval covers, right where the landing points are still in registers: a ballot per covered element is the
 // 64-bit mask of the pairs that bracket it, and the element's lane of the solve kernel later reads one mask per 64-ray block.
 // Counters, 16,384 rows x 905 rays: 1,340 VALU + 553 scalar instructions per wave against 1,200 + 440 without the emission.
-template <bool FAST, bool EMIT>
+// MATCH (the fused sweep, main_rt.py:464-501): the element matcher on the landing points while they are in registers — per
+// covered element a ballot of "within atol + rtol*|x_e|" whose lowest set bit is the wave's first matching ray, one integer
+// atomicMin per element chunk.  No matcher launch (staging the aperture per workgroup, a second read of the landing points).
+template <bool FAST, bool EMIT, bool MATCH>
 __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS_SHOOT_MIN_WAVES, 8))) void rtus_shoot_kernel(ShootArgs a)
 {
     const int n = a.n;
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
         if ((threadIdx.x & 63) == 0 && live) a.land_box[row * ((n + 63) >> 6) + (r_raw >> 6)] = make_double2(lo, hi);
     }
-    if (!live) return;
+    if (!MATCH && !live) return;
+    if (live) {
     if (a.out8) {
         double* o = a.out8 + row * 8 * (size_t)n + r;
         o[0] = P.x; o[(size_t)n] = P.y; o[2 * (size_t)n] = xq; o[3 * (size_t)n] = zq;
@@ -260,23 +269,59 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         }
         if (a.tof) a.tof[row * n + r] = ((t1 + t2) + t3) + t4;         // main_rt.py:497-500
     }
+    }
+    if (MATCH) {
+        const int lane = threadIdx.x & 63;
+        const int B = r_raw >> 6, nb = (n + 63) >> 6;
+        if (B >= nb) return;                                            // (wave-uniform: clones of the last ray past the end of the row)
+        const bool use = live && isfinite(x_in);                        // NaN / inf never match a finite element (np.isclose)
+        double wlo = use ? x_in : INFINITY, whi = use ? x_in : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { wlo = fmin(wlo, __shfl_xor(wlo, o)); whi = fmax(whi, __shfl_xor(whi, o)); }
+        int32_t* __restrict__ mrow = a.m_first + row * (size_t)a.rx_pad;
+        for (int c0 = 0; c0 < a.rx_pad; c0 += 64) {
+            const bool ev = c0 + lane < a.n_rx;
+            const double xv = a.x_rx[min(c0 + lane, a.n_rx - 1)];
+            const double tolv = a.atol + a.rtol * fabs(xv);             // np.isclose(a, b): atol + rtol*|b|, b = the element (unfused in this file)
+            const double xn = __shfl_down(xv, 1);
+            const bool asc = !__ballot(ev && lane < 63 && c0 + lane + 1 < a.n_rx && !(xv <= xn));
+            // ascending chunk: x + tol and x - tol ascend with x (rtol < 1), so the elements a landing point of this wave can
+            // match are [#{x + tol < lo}, #{x - tol <= hi})
+            const int nlo = __popcll(__ballot(ev && xv + tolv < wlo)), nhi = __popcll(__ballot(ev && xv - tolv <= whi));
+            const bool mono = asc && a.rtol < 1.0;
+            const int e0 = mono ? nlo : 0, e1 = mono ? nhi : min(64, a.n_rx - c0);
+            int cand = RTUS_NO_RAY;
+            for (int e = e0; e < e1; ++e) {
+                const double xe = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), e), __builtin_amdgcn_readlane(__double2loint(xv), e));
+                const double te = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tolv), e), __builtin_amdgcn_readlane(__double2loint(tolv), e));
+                const lanemask m = __ballot(use && fabs(x_in - xe) <= te);
+                const int first = (B << 6) + (int)__builtin_ctzll(m | (1ull << 63));
+                cand = (lane == e && m) ? first : cand;
+            }
+            if (cand != RTUS_NO_RAY) atomicMin(&mrow[c0 + lane], cand);
+        }
+        // (rtus_sweep_finalize_kernel turns the winners into first_ray / hit / tof_hit.  Finalizing inside this kernel — the last
+        // wave of a row to arrive, counted by an atomic — was built and measured: no faster for the reference's sweep (29.7 us
+        // against 28.7) and, with a release fence per wave, 85 us: buffer_wbl2 writes the whole L2 back)
+    }
 }
 
 // ---- host-side launchers (called from rtus_capi.hip) -----------------------------------------
 size_t rtus_ws_bytes(int n) { return shoot_ws_bytes(n); }
 
 // polyline + boxes + depth-first records of the alpha grid into the workspace `a` points to
-static void rtus_launch_geometry(const ShootArgs& a, const double* alpha, hipStream_t s)
+static void rtus_launch_geometry(const ShootArgs& a, const double* alpha, hipStream_t s, int32_t* m_init = nullptr, int m_init_n = 0)
 {
     const int n = a.n;
     if (n <= RTUS_GEOM1_TPB) {
         hipLaunchKernelGGL(rtus_geom1_kernel, dim3(1), dim3(RTUS_GEOM1_TPB), 0, s, a.k, alpha, n, (double2*)a.curve, (double*)a.phi_s,
-                           (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1, (double4*)a.node2, a.n0, a.n1, a.n2, (TreeNode*)a.tree);
+                           (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1, (double4*)a.node2, a.n0, a.n1, a.n2, (TreeNode*)a.tree,
+                           m_init, m_init_n);
         return;
     }
     hipLaunchKernelGGL(rtus_curve_kernel, dim3(a.n2), dim3(RTUS_CURVE_TPB), 0, s, a.k, alpha, n,
                        (double2*)a.curve, (double*)a.phi_s, (double2*)a.tan_u, (double4*)a.node0, (double4*)a.node1,
-                       (double4*)a.node2);
+                       (double4*)a.node2, m_init, m_init_n);
     hipLaunchKernelGGL(rtus_tree_kernel, dim3((a.n_tree + 255) / 256), dim3(256), 0, s, a.node0, a.node1, a.node2, a.n0, a.n1, a.n2,
                        a.n3, (TreeNode*)a.tree);
 }
@@ -303,12 +348,84 @@ hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int 
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
     if (pair_mask) {
         if (n_rx <= 0 || n_rx > RTUS_SOLVE_MASK_MAX_RX || !x_rx) return hipErrorInvalidValue;
-        if (fast) hipLaunchKernelGGL((rtus_shoot_kernel<true, true>), grid, dim3(RTUS_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((rtus_shoot_kernel<false, true>), grid, dim3(RTUS_BLOCK), 0, s, a);
+        if (fast) hipLaunchKernelGGL((rtus_shoot_kernel<true, true, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((rtus_shoot_kernel<false, true, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
     } else {
-        if (fast) hipLaunchKernelGGL((rtus_shoot_kernel<true, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((rtus_shoot_kernel<false, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
+        if (fast) hipLaunchKernelGGL((rtus_shoot_kernel<true, false, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((rtus_shoot_kernel<false, false, false>), grid, dim3(RTUS_BLOCK), 0, s, a);
     }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void rtus_sweep_fill_kernel(int4* __restrict__ p, long long n4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_int4(RTUS_NO_RAY, RTUS_NO_RAY, RTUS_NO_RAY, RTUS_NO_RAY);
+}
+
+// the matcher's winners -> first_ray (-1 when none) / hit / tof of the first hitting ray (0.0 when none: main_rt.py:493); the scratch is idle after
+__global__ __launch_bounds__(256) void rtus_sweep_finalize_kernel(int32_t* __restrict__ m_first, int rx_pad, const double* __restrict__ tof, int n,
+                                                                   int n_rx, long long rows, int32_t* __restrict__ first_ray,
+                                                                   uint8_t* __restrict__ hit, double* __restrict__ tof_hit)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * rx_pad) return;
+    const long long row = i / rx_pad;
+    const int e = (int)(i - row * rx_pad);
+    const int f = m_first[i];
+    if (f == RTUS_NO_RAY && e >= n_rx) return;
+    m_first[i] = RTUS_NO_RAY;
+    if (e >= n_rx) return;
+    const bool h = f != RTUS_NO_RAY;
+    const size_t o = (size_t)row * n_rx + e;
+    first_ray[o] = h ? f : -1;
+    if (hit) hit[o] = h ? 1 : 0;
+    if (tof_hit) tof_hit[o] = h ? tof[(size_t)row * n + f] : 0.0;
+}
+
+// ---- the fused sweep: forward trace + element matcher (main_rt.py:464-501) in one kernel ---------------------------------
+// workspace: [forward trace's geometry][m_first: rows x rx_pad int32][tof: rows x n doubles, used when the caller does not ask
+// for the per-ray times]
+static inline size_t sweep_al(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t rtus_sweep_ws_bytes(int n, int n_geom, int n_tx, int n_rx)
+{
+    const size_t rows = (size_t)n_geom * n_tx, rx_pad = ((size_t)n_rx + 63) & ~(size_t)63;
+    return sweep_al(shoot_ws_bytes(n)) + sweep_al(4 * rows * rx_pad) + sweep_al(8 * rows * (size_t)n);
+}
+
+hipError_t rtus_launch_sweep(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a, const double* z_a, int n_tx,
+                             const double* alpha, const double* z_f, int n, const double* x_rx, int n_rx, double atol, double rtol,
+                             int32_t* first_ray, uint8_t* hit, double* tof_hit, double* tof, double* land_x, void* ws, unsigned flags,
+                             hipStream_t s)
+{
+    char* w = (char*)ws;
+    const size_t rows = (size_t)n_geom * n_tx, rx_pad = ((size_t)n_rx + 63) & ~(size_t)63;
+    if (rows * rx_pad > 0x7fffffffull) return hipErrorInvalidValue;
+    ShootArgs a;
+    a.k = make_lens_k(lens);
+    a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = z_f; a.zf_const = 0.0; a.land_box = nullptr; a.pair_mask = nullptr;
+    a.x_rx = x_rx; a.n_rx = n_rx; a.rx_pad = (int)rx_pad;
+    shoot_args_workspace(a, w, n);
+    if ((unsigned long long)a.n_tree * sizeof(TreeNode) >= 0xffffffffull) return hipErrorInvalidValue;
+    int32_t* scratch = (int32_t*)(w + sweep_al(shoot_ws_bytes(n)));
+    a.m_first = scratch;
+    a.atol = atol; a.rtol = rtol;
+    a.out8 = nullptr; a.tof4 = nullptr; a.land_x = land_x; a.status = nullptr;
+    a.tof = tof ? tof : (double*)(w + sweep_al(shoot_ws_bytes(n)) + sweep_al(4 * rows * rx_pad));
+    a.n_tx = n_tx; a.n_geom = n_geom; a.flags = flags;
+    if (!(flags & RTUS_POLYLINE_READY)) {
+        // the matcher's scratch starts idle: inside the polyline kernel when that costs it at most 64 stores per thread, by a fill
+        // kernel otherwise (RTUS_POLYLINE_READY: the finalize kernel of the previous launch on this workspace left it idle)
+        const size_t geom_threads = n <= RTUS_GEOM1_TPB ? RTUS_GEOM1_TPB : (size_t)a.n2 * RTUS_CURVE_TPB;
+        const bool ride = rows * rx_pad <= 64 * geom_threads;
+        if (!ride) hipLaunchKernelGGL(rtus_sweep_fill_kernel, dim3((unsigned)((rows * rx_pad + 1023) / 1024)), dim3(256), 0, s, (int4*)scratch, (long long)(rows * rx_pad / 4));
+        rtus_launch_geometry(a, alpha, s, ride ? scratch : nullptr, ride ? (int)(rows * rx_pad) : 0);
+    }
+    const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
+    if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL((rtus_shoot_kernel<true, false, true>), grid, dim3(RTUS_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((rtus_shoot_kernel<false, false, true>), grid, dim3(RTUS_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(rtus_sweep_finalize_kernel, dim3((unsigned)((rows * rx_pad + 255) / 256)), dim3(256), 0, s, a.m_first, (int)rx_pad,
+                           a.tof, n, n_rx, (long long)rows, first_ray, hit, tof_hit);
     return hipGetLastError();
 }
 

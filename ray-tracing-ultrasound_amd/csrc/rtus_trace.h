@@ -51,6 +51,9 @@ struct ShootArgs {
     unsigned long long* __restrict__ pair_mask;   // [n_geom][n_tx][ceil(n/64)][rx_pad]: bit i of [row][B][e] = pair (64B+i, 64B+i+1) brackets element e (i < 63)
     const double* __restrict__ x_rx;    // [n_rx] receive elements (n_rx <= RTUS_SOLVE_MASK_MAX_RX)
     int n_rx, rx_pad;                   // rx_pad = n_rx rounded up to a multiple of 64
+    // the fused sweep (rtus_shoot_kernel<., ., true>): the element matcher of main_rt.py:487-501 asked while the landing points are in registers
+    int32_t* __restrict__ m_first;      // scratch [rows][rx_pad]: smallest matching ray index so far, RTUS_NO_RAY when idle
+    double atol, rtol;
     double zf_const;
     int n, n_tx, n_geom, n0, n1, n2, n3, n_tree;    // n3: 4096-point boxes, only when n2 > 8 (else 0); they live in the tree only
     unsigned flags;
@@ -62,6 +65,7 @@ struct ShootArgs {
 // Everything that is one bit per ray lives in 64-bit lane masks (SGPR pairs): v_cmp writes them
 // directly and the bookkeeping is scalar-ALU work.
 typedef unsigned long long lanemask;
+#define RTUS_NO_RAY 0x7f7f7f7f   // hipMemsetAsync(0x7f) sentinel of the matcher's "first ray"; larger than any ray index
 #ifdef RTUS_EXP_COUNT
 static __device__ unsigned long long rtus_dbg[8];   // (one copy per translation unit; rtus_dbg_read reads rtus_shoot.hip's)
 #define DBG(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&rtus_dbg[i], 1ull); } while (0)
@@ -592,3 +596,9 @@ hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int 
                                 double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,
                                 double2* land_box, unsigned long long* pair_mask, const double* x_rx, int n_rx,
                                 void* ws, unsigned flags, hipStream_t s);
+// the fused sweep: forward trace + element matcher in one kernel (main_rt.py:464-501)
+size_t rtus_sweep_ws_bytes(int n, int n_geom, int n_tx, int n_rx);
+hipError_t rtus_launch_sweep(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a, const double* z_a, int n_tx,
+                             const double* alpha, const double* z_f, int n, const double* x_rx, int n_rx, double atol, double rtol,
+                             int32_t* first_ray, uint8_t* hit, double* tof_hit, double* tof, double* land_x, void* ws, unsigned flags,
+                             hipStream_t s);

@@ -57,6 +57,43 @@ class ShootPlan:
         return o
 
 
+class SweepPlan:
+    """Pre-allocated workspace + outputs for the fused sweep (rtus_sweep_dev: forward trace + element matcher in one kernel,
+    main_rt.py:464-501): first_ray i32 / hit u8 / tof_hit f64 [G, T, E], plus the per-ray arrays in ``want`` ("tof", "land_x":
+    [G, T, N]).  No allocation, no sync inside ``run`` — capturable in a hipGraph."""
+
+    def __init__(self, n_geom, n_tx, n_rays, n_rx, *, want=(), params: Params = None, fast=False, atol=1e-6, rtol=1e-5, device="cuda"):
+        self.p = _resolve(params)
+        self.G, self.T, self.N, self.E = int(n_geom), int(n_tx), int(n_rays), int(n_rx)
+        self.ws_bytes = int(_lib.lib().rtus_sweep_workspace_bytes(self.N, self.G, self.T, self.E))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        G, T, N, E = self.G, self.T, self.N, self.E
+        self.out = {"first_ray": torch.empty((G, T, E), dtype=torch.int32, device=device),
+                    "hit": torch.empty((G, T, E), dtype=torch.uint8, device=device),
+                    "tof_hit": torch.empty((G, T, E), dtype=torch.float64, device=device)}
+        for w in want:
+            if w not in ("tof", "land_x"):
+                raise ValueError(f"unknown output {w!r}")
+            self.out[w] = torch.empty((G, T, N), dtype=torch.float64, device=device)
+        self.lens = self.p.lens()
+        self.flags = 1 if fast else 0
+        self.atol, self.rtol = float(atol), float(rtol)
+
+    def run(self, geoms, x_a, z_a, alpha, z_f, x_rx, polyline_ready=False):
+        """polyline_ready: the previous ``run`` of this plan used the same ``alpha`` (RTUS_POLYLINE_READY)."""
+        _chk(geoms, "geoms"); _chk(x_a, "x_a"); _chk(z_a, "z_a"); _chk(alpha, "alpha"); _chk(z_f, "z_f"); _chk(x_rx, "x_rx")
+        if geoms.shape != (self.G, 2) or x_a.numel() != self.T or z_a.numel() != self.T \
+                or alpha.numel() != self.N or z_f.numel() != self.N or x_rx.numel() != self.E:
+            raise ValueError("tensor shapes do not match the plan")
+        o = self.out
+        st = _lib.lib().rtus_sweep_dev(C.byref(self.lens), _p(geoms), self.G, _p(x_a), _p(z_a), self.T, _p(alpha), _p(z_f), self.N,
+                                       _p(x_rx), self.E, self.atol, self.rtol, _p(o["first_ray"]), _p(o["hit"]), _p(o["tof_hit"]),
+                                       _p(o.get("tof")), _p(o.get("land_x")), _p(self.ws), self.ws_bytes,
+                                       self.flags | (8 if polyline_ready else 0), _stream())
+        _lib.check(st, "rtus_sweep_dev")
+        return o
+
+
 class SolvePlan:
     """Pre-allocated workspace + outputs for repeated root-finding solves of one shape (rtus_solve_dev): no allocation,
     no sync inside ``run`` — capturable in a hipGraph.  tt / alpha_root [G, T, E]; with all_roots also tt_all / alpha_all

@@ -36,9 +36,13 @@ def sweep_database(*, params=None, n_rays=181 * 5, num_elements=64, pitch=0.0006
     zf = np.ones((n_rays,), dtype=np.float64) * p.d                        # :477
     alpha = np.linspace(-api.ALPHA_MAX, api.ALPHA_MAX, n_rays)             # :479
     geoms = sweep_geometries(radii_cm, offsets_mm)
-    b = be.shoot_batch([x_a[element_idx]], [z_a[element_idx]], zf, alpha, geoms, params=p,
-                       want=("tof", "land_x"))                             # :482, all geometries at once
-    hit, tof, _ = be.match_elements(b["land_x"][:, 0], b["tof"][:, 0], x_a, atol=atol)   # :487-501
+    if hasattr(be, "sweep_batch"):                                         # :482-501 for all geometries in one kernel
+        b = be.sweep_batch([x_a[element_idx]], [z_a[element_idx]], zf, alpha, x_a, geoms, atol=atol, params=p)
+        hit, tof = b["hit"][:, 0], b["tof_hit"][:, 0]
+    else:                                                                  # a backend with the two reference-shaped calls only
+        b = be.shoot_batch([x_a[element_idx]], [z_a[element_idx]], zf, alpha, geoms, params=p,
+                           want=("tof", "land_x"))                         # :482, all geometries at once
+        hit, tof, _ = be.match_elements(b["land_x"][:, 0], b["tof"][:, 0], x_a, atol=atol)   # :487-501
     rows = []
     for g in range(geoms.shape[0]):
         for e in range(x_a.size):

@@ -155,7 +155,7 @@ def test_kernel_resources_of_the_trace_kernels():
                         res.setdefault(name, {})[key] = int(ln.split()[1])
     shoot = {k: v for k, v in res.items() if "rtus_shoot_kernel" in k}
     solve = {k: v for k, v in res.items() if "rtus_solve_kernel" in k}
-    assert len(shoot) == 4 and len(solve) >= 4
+    assert len(shoot) == 6 and len(solve) >= 4                       # {compat, vector form} x {plain, bracket emission, fused matcher}
     for k, v in shoot.items():
         assert v[".private_segment_fixed_size:"] == 0 and v[".vgpr_spill_count:"] == 0 and v[".vgpr_count:"] <= 80, (k, v)
     for k, v in solve.items():

@@ -1,0 +1,146 @@
+"""GPU: the fused sweep (rtus_sweep*: the element matcher of main_rt.py:487-501 inside the forward-trace kernel) gives the bits of the two
+calls it replaces — checked against the reference's own database_2.csv, against the C oracle's matcher on the traced landing
+points, over ragged ray counts, apertures in any order, tolerances that put many rays on one element, and replays on one
+workspace (the matcher's scratch is left idle by the kernel itself)."""
+import csv
+import os
+from importlib import import_module
+
+import ctypes as C
+import numpy as np
+import pytest
+
+from conftest import D_PLANE, GOLDEN, load_golden
+
+TIME_TOL = 1e-15    # seconds (bar: 1e-9 s)
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_calls(rtus, xa, za, zf, alpha, x_rx, geoms, atol, **kw):
+    b = rtus.shoot_batch(xa, za, zf, alpha, geoms, params=rtus.Params(), want=("tof", "land_x"), **kw)
+    hit, th, first = rtus.match_elements(b["land_x"], b["tof"], x_rx, atol=atol)
+    return b, hit, th, first
+
+
+def test_reference_sweep_in_one_kernel_equals_database2(rtus):
+    s = load_golden("sweep_cfg.npz")
+    alpha, geoms, x_elem = s["alpha"], s["geoms"], s["x_elem"]
+    zf = np.full(alpha.size, D_PLANE)
+    f = rtus.sweep_batch([0.0], [D_PLANE], zf, alpha, x_elem, geoms, atol=1e-6, params=rtus.Params(), want=("tof", "land_x"))
+    b, hit, th, first = _two_calls(rtus, [0.0], [D_PLANE], zf, alpha, x_elem, geoms, 1e-6)
+    assert np.array_equal(f["hit"], hit) and np.array_equal(f["first_ray"], first) and np.array_equal(f["tof_hit"], th)
+    assert np.array_equal(f["tof"], b["tof"], equal_nan=True) and np.array_equal(f["land_x"], b["land_x"], equal_nan=True)
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "database_2.csv"))))[1:]
+    db_hit = np.array([r[3] == "True" for r in rows]).reshape(210, 65)
+    db_tof = np.array([float(r[4]) for r in rows]).reshape(210, 65)
+    assert np.array_equal(f["hit"][:, 0], db_hit)
+    assert np.max(np.abs(f["tof_hit"][:, 0] - db_tof)) < TIME_TOL
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 905, 1025, 4099])
+def test_fused_matcher_vs_oracle_matcher(rtus, n):
+    """ragged ray counts (part waves, rows of several workgroups, the multi-kernel geometry path above 1024 rays) x apertures
+    sorted / reversed / shuffled x tolerances from 'one ray' to 'hundreds of rays per element: the FIRST index wins'"""
+    from oracle import cport
+    rng = np.random.default_rng(100 + n)
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    geoms = np.stack([rng.uniform(0.01, 0.1, 5), rng.uniform(-0.01, 0.01, 5)], axis=1)
+    xa = np.array([0.0, -0.0123, 0.0081])
+    za = np.full(3, D_PLANE)
+    for e, atol in ((1, 1e-3), (64, 1e-6), (65, 1e-4), (257, 2e-3)):
+        base = np.sort(rng.uniform(-0.03, 0.03, e))
+        for x_rx in (base, base[::-1].copy(), rng.permutation(base)):
+            f = rtus.sweep_batch(xa, za, zf, alpha, x_rx, geoms, atol=atol, params=rtus.Params(), want=("tof", "land_x"))
+            b, hit, th, first = _two_calls(rtus, xa, za, zf, alpha, x_rx, geoms, atol)
+            assert np.array_equal(f["land_x"], b["land_x"], equal_nan=True) and np.array_equal(f["tof"], b["tof"], equal_nan=True)
+            assert np.array_equal(f["hit"], hit) and np.array_equal(f["first_ray"], first) and np.array_equal(f["tof_hit"], th)
+            for g in (0, 4):
+                for t in (0, 2):
+                    t4 = np.zeros((4, n)); t4[0] = f["tof"][g, t]
+                    oh, ot, of = cport.match(f["land_x"][g, t], t4, x_rx, atol)
+                    assert np.array_equal(f["hit"][g, t], oh) and np.array_equal(f["first_ray"][g, t], of)
+                    assert np.array_equal(f["tof_hit"][g, t], ot)
+    # vector-form arithmetic: same matcher on that mode's landing points
+    f = rtus.sweep_batch(xa, za, zf, alpha, base, geoms, atol=1e-5, params=rtus.Params(), fast=True)
+    b, hit, th, first = _two_calls(rtus, xa, za, zf, alpha, base, geoms, 1e-5, fast=True)
+    assert np.array_equal(f["hit"], hit) and np.array_equal(f["first_ray"], first) and np.array_equal(f["tof_hit"], th)
+
+
+def test_plan_replays_on_one_workspace_and_in_a_graph(rtus):
+    """The finalize kernel leaves the matcher's scratch idle: a second run with RTUS_POLYLINE_READY (no geometry kernel, no fill) and other
+    geometries is right, and so is a captured hipGraph replayed several times."""
+    import torch
+    dev_api = import_module("ray-tracing-ultrasound_amd.device")
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    s = load_golden("sweep_cfg.npz")
+    alpha, x_elem = s["alpha"], s["x_elem"]
+    zf = np.full(alpha.size, D_PLANE)
+    g1, g2 = s["geoms"][::2], s["geoms"][1::2]
+    G, N, E = g1.shape[0], alpha.size, x_elem.size
+    plan = dev_api.SweepPlan(G, 1, N, E, params=rtus.Params(), atol=1e-6)
+    a = [t64([0.0]), t64([D_PLANE]), t64(alpha), t64(zf), t64(x_elem)]
+    tg = t64(g1)
+    for geoms, ready in ((g1, False), (g2, True), (g1, True), (g2, False)):
+        tg.copy_(t64(geoms))
+        o = plan.run(tg, *a, polyline_ready=ready)
+        torch.cuda.synchronize()
+        _, hit, th, first = _two_calls(rtus, [0.0], [D_PLANE], zf, alpha, x_elem, geoms, 1e-6)
+        assert np.array_equal(o["hit"].cpu().numpy().astype(bool), hit) and np.array_equal(o["first_ray"].cpu().numpy(), first)
+        assert np.array_equal(o["tof_hit"].cpu().numpy(), th)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        plan.run(tg, *a)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            plan.run(tg, *a)
+    for geoms in (g1, g2, g1):
+        tg.copy_(t64(geoms))
+        for v in plan.out.values():
+            v.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        _, hit, th, first = _two_calls(rtus, [0.0], [D_PLANE], zf, alpha, x_elem, geoms, 1e-6)
+        assert np.array_equal(plan.out["hit"].cpu().numpy().astype(bool), hit)
+        assert np.array_equal(plan.out["first_ray"].cpu().numpy(), first) and np.array_equal(plan.out["tof_hit"].cpu().numpy(), th)
+
+
+def test_many_rows_take_the_fill_path(rtus):
+    """more scratch than the one-workgroup geometry kernel initialises itself (rows x 64 > 65,536): a fill kernel instead"""
+    rng = np.random.default_rng(3)
+    n = 130
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    geoms = np.stack([rng.uniform(0.02, 0.08, 40), rng.uniform(-0.008, 0.008, 40)], axis=1)
+    xa = np.linspace(-0.015, 0.015, 30)
+    za = np.full(30, D_PLANE)
+    x_rx = rtus.reference_elements()
+    f = rtus.sweep_batch(xa, za, zf, alpha, x_rx, geoms, atol=2e-4, params=rtus.Params())
+    _, hit, th, first = _two_calls(rtus, xa, za, zf, alpha, x_rx, geoms, 2e-4)
+    assert hit.any() and np.array_equal(f["hit"], hit) and np.array_equal(f["first_ray"], first) and np.array_equal(f["tof_hit"], th)
+
+
+def test_sweep_argument_errors(rtus):
+    L = rtus.lib()
+    lens = rtus.Params().lens()
+    d = np.zeros(8)
+    i32 = np.zeros(8, dtype=np.int32)
+    p = lambda a: a.ctypes.data
+    ok = dict(n_geom=1, n_tx=1, n=4, n_rx=2, atol=1e-6, rtol=1e-5, first=p(i32), flags=0)
+    def call(**kw):
+        k = dict(ok); k.update(kw)
+        return L.rtus_sweep(C.byref(lens), p(d), k["n_geom"], p(d), p(d), k["n_tx"], p(d), p(d), k["n"], p(d), k["n_rx"], k["atol"], k["rtol"],
+                            k["first"], None, None, None, None, k["flags"], 0)
+    assert call(n_rx=0) == -1 and call(atol=-1.0) == -1 and call(rtol=float("nan")) == -1 and call(first=None) == -1
+    assert call(n=1) == -1 and call(flags=0x100) == -1
+    assert L.rtus_sweep_workspace_bytes(0, 1, 1, 1) == 0 and L.rtus_sweep_workspace_bytes(905, 210, 1, 65) % 256 == 0
+    import torch
+    ws = torch.empty(64, dtype=torch.uint8, device="cuda")
+    t = torch.zeros(8, dtype=torch.float64, device="cuda")
+    fr = torch.zeros(8, dtype=torch.int32, device="cuda")
+    st = L.rtus_sweep_dev(C.byref(lens), t.data_ptr(), 1, t.data_ptr(), t.data_ptr(), 1, t.data_ptr(), t.data_ptr(), 4, t.data_ptr(), 2,
+                          1e-6, 1e-5, fr.data_ptr(), None, None, None, None, ws.data_ptr(), 64, 0, None)
+    assert st == -4                                                  # RTUS_ERR_WORKSPACE
