@@ -41,6 +41,9 @@ for mode in 0 1; do
   rocprofv3 --pmc $SQSH -d $OUT/sq_shoot${mode}b -o sq --output-format csv -- python3 $ROOT/scripts/run_shoot_once.py $mode > $OUT/sq_shoot${mode}b.log 2>&1
 done
 rocprofv3 --kernel-trace --stats -d $OUT/kt_sweep -o kt --output-format csv -- python3 $B --workload ref_sweep --steps 50 --warmup 5 --graph off --no-extra --no-cpu-baseline > $OUT/kt_sweep.log 2>&1
+for form in two fused kept; do
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_sweep_$form -o kt --output-format csv -- python3 $ROOT/scripts/run_sweep_once.py $form > $OUT/kt_sweep_$form.log 2>&1
+done
 echo "[7] consumers: traffic of the TFM gather kernel and of the focal-law stream"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/rd_cons -o rd --output-format csv -- python3 $ROOT/scripts/run_consumers_once.py > $OUT/rd_cons.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/wr_cons -o wr --output-format csv -- python3 $ROOT/scripts/run_consumers_once.py > $OUT/wr_cons.log 2>&1

@@ -167,7 +167,10 @@ for wl, like in (("cfg4_lens_f32", "rtus_tt_lens_kernel"), ("cfg2_planar", "rtus
 # ---- forward trace: one size per row -------------------------------------------------------------------------------
 shoot = (kernel_rows("kt_shoot0", "reference geometry 1024 tx x 8192 rays, reference-compatible arithmetic (scripts/run_shoot_once.py 0)") +
          kernel_rows("kt_shoot1", "reference geometry 1024 tx x 8192 rays, vector-form arithmetic (scripts/run_shoot_once.py 1)") +
-         kernel_rows("kt_sweep", "the reference's own sweep, 210 geometries x 905 rays (bench.py --workload ref_sweep --graph off)"))
+         kernel_rows("kt_sweep", "the reference's own sweep, 210 geometries x 905 rays (bench.py --workload ref_sweep --graph off: the fused entry)") +
+         kernel_rows("kt_sweep_two", "the same sweep as two calls, rtus_shoot_dev + rtus_match_dev (scripts/run_sweep_once.py two)") +
+         kernel_rows("kt_sweep_fused", "the same sweep through rtus_sweep_dev (scripts/run_sweep_once.py fused)") +
+         kernel_rows("kt_sweep_kept", "the same sweep through rtus_sweep_dev with the polyline kept, RTUS_POLYLINE_READY (scripts/run_sweep_once.py kept)"))
 write_rows(os.path.join(dst, f"{tag}_shoot_kernel_rows.csv"), shoot)
 for mode, name in ((0, "compat"), (1, "fast")):
     t, m = counters([f"sq_shoot{mode}", f"sq_shoot{mode}b"], "rtus_shoot_kernel")
