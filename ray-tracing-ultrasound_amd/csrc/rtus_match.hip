@@ -35,7 +35,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
     for (int e = threadIdx.x; e < a.n_rx; e += RTUS_BLOCK) {
         const double xe = a.x_rx[e];
         sx[e] = xe;
-        stol[e] = __dadd_rn(a.atol, __dmul_rn(a.rtol, fabs(xe)));      // np.isclose: atol + rtol*|b|, b = elem_x (two roundings, as NumPy)
+        // np.isclose(a, b): |a - b| <= atol + rtol*|b|, b = elem_x (two roundings, as NumPy) for finite operands, a == b when either
+        // is infinite, never with a NaN.  A negative tolerance keeps an infinite element out of the first test.
+        stol[e] = isfinite(xe) ? __dadd_rn(a.atol, __dmul_rn(a.rtol, fabs(xe))) : -1.0;
         asc = asc && isfinite(xe) && (e == 0 || a.x_rx[e - 1] <= xe);
         amax = fmax(amax, fabs(xe));
     }
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
         if (r >= a.n) return;                      // (no barrier below: a thread may leave alone)
         const double x = a.land_x[(size_t)row * a.n + r];
         bool any = false;
-        if (isfinite(x)) {                         // NaN / inf never match a finite element
+        if (x == x) {                              // NaN never matches; an infinite landing point only an equal infinite element
             int e0 = 0, e1 = a.n_rx;
             if (sorted) {                          // lower_bound(x - win)
                 const double lo = x - win;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_match_kernel(MatchArgs a)
             for (int e = e0; e < e1; ++e) {
                 const double xe = sx[e];
                 if (sorted && xe > x + win) break;
-                if (fabs(x - xe) <= stol[e]) {
+                if (fabs(x - xe) <= stol[e] || (isinf(xe) && x == xe)) {
                     any = true;
                     if (a.first_ray) atomicMin(&a.first_ray[(size_t)row * a.n_rx + e], r);
                     else break;

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         const int lane = threadIdx.x & 63;
         const int B = r_raw >> 6, nb = (n + 63) >> 6;
         if (B >= nb) return;                                            // (wave-uniform: clones of the last ray past the end of the row)
-        const bool use = live && isfinite(x_in);                        // NaN / inf never match a finite element (np.isclose)
+        // np.isclose(x_land, x_e): |x_land - x_e| <= atol + rtol*|x_e| for finite operands, x_land == x_e when either is infinite,
+        // never with a NaN
+        const bool use = live && x_in == x_in;
         double wlo = use ? x_in : INFINITY, whi = use ? x_in : -INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { wlo = fmin(wlo, __shfl_xor(wlo, o)); whi = fmax(whi, __shfl_xor(whi, o)); }
@@ -284,7 +286,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
         for (int c0 = 0; c0 < a.rx_pad; c0 += 64) {
             const bool ev = c0 + lane < a.n_rx;
             const double xv = a.x_rx[min(c0 + lane, a.n_rx - 1)];
-            const double tolv = a.atol + a.rtol * fabs(xv);             // np.isclose(a, b): atol + rtol*|b|, b = the element (unfused in this file)
+            const double tolv = isfinite(xv) ? a.atol + a.rtol * fabs(xv) : -1.0;   // (unfused in this file: two roundings, as NumPy; negative: an
+                                                                                    // infinite element stays out of the first test)
             const double xn = __shfl_down(xv, 1);
             const bool asc = !__ballot(ev && lane < 63 && c0 + lane + 1 < a.n_rx && !(xv <= xn));
             // ascending chunk: x + tol and x - tol ascend with x (rtol < 1), so the elements a landing point of this wave can
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
             for (int e = e0; e < e1; ++e) {
                 const double xe = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), e), __builtin_amdgcn_readlane(__double2loint(xv), e));
                 const double te = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tolv), e), __builtin_amdgcn_readlane(__double2loint(tolv), e));
-                const lanemask m = __ballot(use && fabs(x_in - xe) <= te);
+                const lanemask m = __ballot(use && (fabs(x_in - xe) <= te || (isinf(xe) && x_in == xe)));
                 const int first = (B << 6) + (int)__builtin_ctzll(m | (1ull << 63));
                 cand = (lane == e && m) ? first : cand;
             }

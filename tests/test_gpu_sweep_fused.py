@@ -144,3 +144,36 @@ def test_sweep_argument_errors(rtus):
     st = L.rtus_sweep_dev(C.byref(lens), t.data_ptr(), 1, t.data_ptr(), t.data_ptr(), 1, t.data_ptr(), t.data_ptr(), 4, t.data_ptr(), 2,
                           1e-6, 1e-5, fr.data_ptr(), None, None, None, None, ws.data_ptr(), 64, 0, None)
     assert st == -4                                                  # RTUS_ERR_WORKSPACE
+
+
+def test_non_finite_elements_and_landing_points_follow_np_isclose(rtus):
+    """np.isclose(a, b) is a == b when either operand is infinite and False with a NaN (oracle: np_isclose): an infinite receive
+    element is hit by no finite landing point, a NaN element by none — in both matchers, whatever the aperture's order."""
+    from oracle import cport
+    rng = np.random.default_rng(8)
+    n = 777
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+    geoms = np.array([[0.037, 0.0038], [0.05, -0.002]])
+    base = np.sort(rng.uniform(-0.02, 0.02, 70))
+    for x_rx in (np.concatenate([[-np.inf], base, [np.inf]]), np.concatenate([base[:30], [np.nan, np.inf], base[30:], [-np.inf]])):
+        f = rtus.sweep_batch([0.0], [D_PLANE], zf, alpha, x_rx, geoms, atol=1e-4, params=rtus.Params(), want=("tof", "land_x"))
+        hit, th, first = rtus.match_elements(f["land_x"], f["tof"], x_rx, atol=1e-4)
+        assert np.array_equal(f["hit"], hit) and np.array_equal(f["first_ray"], first) and np.array_equal(f["tof_hit"], th)
+        for g in range(2):
+            t4 = np.zeros((4, n)); t4[0] = f["tof"][g, 0]
+            oh, ot, of = cport.match(f["land_x"][g, 0], t4, x_rx, 1e-4)
+            assert np.array_equal(f["hit"][g, 0], oh) and np.array_equal(f["first_ray"][g, 0], of) and np.array_equal(f["tof_hit"][g, 0], ot)
+        assert f["hit"].any() and not f["hit"][..., ~np.isfinite(x_rx)].any()
+        # the stand-alone matcher also takes landing points that are infinite: they hit the equal infinity and nothing else
+        land = f["land_x"][:, 0].copy()
+        land[:, 5] = np.inf; land[:, 9] = -np.inf; land[:, 2] = np.inf
+        tof = f["tof"][:, 0]
+        hit, th, first = rtus.match_elements(land, tof, x_rx, atol=1e-4)
+        rh = rtus.ray_hits(land, x_rx, atol=1e-4)
+        for g in range(2):
+            t4 = np.zeros((4, n)); t4[0] = tof[g]
+            oh, ot, of = cport.match(land[g], t4, x_rx, 1e-4)
+            assert np.array_equal(hit[g], oh) and np.array_equal(first[g], of) and np.array_equal(th[g], ot, equal_nan=True)   # (the moved rays' own times may be NaN)
+            assert np.array_equal(rh[g], cport.ray_hits(land[g], x_rx, 1e-4))
+        assert first[0, list(x_rx).index(np.inf)] == 2 and first[0, list(x_rx).index(-np.inf)] == 9
