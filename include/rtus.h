@@ -171,7 +171,8 @@ int rtus_solve(const rtus_lens *lens, const double *geoms, int n_geom,
 /* ------------------------------------------------------------------------------------------
  * Element matcher — replaces the scan of main_rt.py:487-501: for each receive element the FIRST
  * ray (ascending index) with np.isclose(land_x[ray], x_rx[e], rtol, atol), i.e.
- * |land_x - x_rx| <= atol + rtol*|x_rx| (NaN never matches).  n_batch = n_geom*n_tx rows.
+ * |land_x - x_rx| <= atol + rtol*|x_rx| for finite operands, land_x == x_rx when either is infinite,
+ * never with a NaN (np.isclose's rules).  n_batch = n_geom*n_tx rows.
  *
  *   land_x, tof [n_batch][n_rays]    (outputs of rtus_shoot*)
  *   x_rx        [n_rx]
