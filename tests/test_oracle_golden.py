@@ -199,3 +199,18 @@ def test_loop_structured_numpy_port_vs_reference():
     for tag in ("q1nan", "tir", "off0", "offtx"):
         r_o, off, x_tx = e[tag + "_cfg"]
         _check8(rt_numpy_loop.shoot(x_tx, D_PLANE, np.full(905, D_PLANE), e["alpha"], r_o, off), e[tag], "numpy-loop/" + tag)
+
+
+def test_oracle_vs_reference_on_inputs_its_drivers_never_use():
+    """tests/golden/random_cfg.npz (make_golden_random.py ran the reference): non-uniform, narrow and DESCENDING launch-angle
+    grids, a landing depth that differs from ray to ray, random geometries and transmit positions."""
+    g = load_golden("random_cfg.npz")
+    worst = 0.0
+    for i in range(int(g["n_cases"])):
+        tag = f"c{i:02d}"
+        assert int(g[tag + "_raises"]) == 0
+        n, r_outer, off, x_tx = g[tag + "_cfg"]
+        o, _ = cport.shoot(float(x_tx), D_PLANE, g[tag + "_zf"], g[tag + "_alpha"], float(r_outer), float(off))
+        _check8(o, g[tag + "_out8"], tag)
+        worst = max(worst, max(max_abs(o[k], g[tag + "_out8"][k]) for k in range(8)))
+    assert worst < POS_TOL
