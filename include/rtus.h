@@ -142,7 +142,8 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
  * The ray chain is exactly rtus_shoot's (same flags); the alpha grid only brackets the roots and defines the
  * lens polyline.  x_land(alpha) is U-shaped: an element usually has two ray paths.
  *
- *   alpha [n_rays]  bracketing grid (ascending) = the lens polyline grid        main_rt.py:479, 338
+ *   alpha [n_rays]  bracketing grid, STRICTLY ASCENDING = the lens polyline grid  main_rt.py:479, 338
+ *                   (rtus_solve checks it: RTUS_ERR_INVALID_ARG; rtus_solve_dev cannot — device memory)
  *   x_rx  [n_rx]    receive elements on the plane z = z_land                     main_rt.py:469-477
  *   tt        [n_geom][n_tx][n_rx]      least travel time over the element's roots; NaN if none
  *   alpha_root[n_geom][n_tx][n_rx]      nullable: launch angle of that path

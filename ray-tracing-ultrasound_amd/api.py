@@ -364,6 +364,8 @@ def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params
         raise ValueError("x_a and z_a must have the same length")
     if alpha.size < 2:
         raise ValueError("Curve needs at least two points.")
+    if not np.all(np.diff(alpha) > 0):
+        raise ValueError("alpha must be strictly ascending (its intervals are the root brackets)")
     geoms = (np.asarray([[p.r_outer, p.pipe_offset]], dtype=np.float64) if geoms is None
              else _f64(geoms, "geoms", 2))
     G, T, E = geoms.shape[0], x_a.size, x_rx.size

@@ -385,6 +385,8 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
 {
     int st = check_solve(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, n_rays, x_rx, n_rx, z_land, tt, flags);
     if (st) return st;
+    for (int i = 0; i + 1 < n_rays; ++i)                    // the brackets are intervals of the grid: strictly ascending (host arrays can be checked)
+        if (!(alpha[i] < alpha[i + 1])) return RTUS_ERR_INVALID_ARG;
     const size_t tot = (size_t)n_geom * n_tx * n_rx;
     const size_t wsb = rtus_solve_ws_bytes(n_rays, n_geom, n_tx, n_rx);
     const size_t need = al256(16 * (size_t)n_geom) + 2 * al256(8 * (size_t)n_tx) + al256(8 * (size_t)n_rays) + al256(8 * (size_t)n_rx) +

@@ -59,6 +59,8 @@ def test_invalid_arguments_are_status_codes_not_crashes(rtus):
     assert L.rtus_sweep(C.byref(lens), p, 1, p, p, 1, p, p, 4, p, 2, 1e-6, 1e-5, None, None, None, None, None, 0, 0) == -1    # first_ray is not optional
     assert L.rtus_sweep_dev(C.byref(lens), p, 1, p, p, 1, p, p, 4, p, 2, 1e-6, 1e-5, fr, None, None, None, None, None, 0, 0, None) == -4
     assert L.rtus_sweep_workspace_bytes(905, 210, 1, 65) >= L.rtus_shoot_workspace_bytes(905) + 210 * 128 * 4 + 210 * 905 * 8
+    desc = np.array([0.3, 0.2, 0.1, 0.0])
+    assert L.rtus_solve(C.byref(lens), p, 1, p, p, 1, desc.ctypes.data, 4, p, 1, 0.21, p, None, None, None, None, 0, 0) == -1   # descending bracketing grid
     z = np.array([0.02, 0.01])                                  # not ascending
     c = np.array([1500.0, 1500.0, 1500.0])
     assert L.rtus_tt_layers(z.ctypes.data, c.ctypes.data, 2, p, p, 1, p, p, 1, p, None, 0) == -1
@@ -81,6 +83,8 @@ def test_python_wrapper_validation(rtus):
         rtus.sweep_batch([0.0], [0.21], a[:5], a, [0.0], params=p)      # alpha / z_f mismatch
     with pytest.raises(ValueError):
         rtus.sweep_batch([0.0], [0.21], a, a, [0.0], params=p, want=("out8",))   # only the matcher's per-ray inputs can be asked for
+    with pytest.raises(ValueError):
+        rtus.solve_travel_times([0.0], [0.21], [0.0], a[::-1], params=p)   # the bracketing grid must ascend
     with pytest.raises(ValueError):
         rtus.travel_time_layers([0.01], [1500.0], [0.0], [0.0], [0.0], [0.02])
     assert p.d == float(np.float64(p.l0) + np.float64(p.h0))
