@@ -15,6 +15,21 @@
 // starts each solve from the previous element's alpha (continuation).
 #include "rtus_device.h"
 
+#ifdef RTUS_EXP_COUNT   // experiment builds only (scripts/exp_lens_tonly.py): how often the T-only rows run
+static __device__ unsigned long long lens_dbg[8];
+#define LDBG(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&lens_dbg[i], 1ull); } while (0)
+extern "C" int rtus_dbg_read_lens(unsigned long long* out)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(lens_dbg), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(lens_dbg), z, sizeof(z));
+    return 0;
+}
+#else
+#define LDBG(i) do {} while (0)
+#endif
+
 template <typename R> struct LensFermatArgs {
     R c1inv, c2inv;          // 1/c1, 1/c2
     R phi_3, twoTc, C4A, inv2A;   // lens constants (see LensK)
@@ -142,6 +157,24 @@ __device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, 
     }
 }
 
+// T(alpha) alone: no P', no g.  T is stationary in alpha at the ray (Fermat), so evaluated delta away from the minimiser it is off by
+// g' delta^2 / 2 — with g' ~ 1e-4 s/rad^2 and delta <= 1e-5 rad that is 5e-15 s, a thousandth of an fp32 ulp of T.
+template <typename R, bool POLY>
+__device__ __forceinline__ R lens_time_only(const LensConst<R>& k, R alpha, R xa, R za, R xf, R zf)
+{
+    R s, c;
+    if (POLY) sincos_poly<R>(alpha, s, c);
+    else sincos_r<R>(alpha, &s, &c);
+    const R B = k.phi_3 * c - k.twoTc;                      // main_rt.py:184
+    const R disc = B * B - k.C4A;
+    const R S = disc * rsqrt_r<R>(disc);
+    const R h = -(B + S) * k.inv2A;                         // :171-177 root [1]
+    const R px = h * s, pz = h * c;                         // :220-221
+    const R ax = px - xa, az = pz - za, fx = px - xf, fz = pz - zf;
+    const R da = ax * ax + az * az, df = fx * fx + fz * fz;
+    return da * rsqrt_r<R>(da) * k.c1inv + df * rsqrt_r<R>(df) * k.c2inv;
+}
+
 typedef unsigned int lens_u32x2 __attribute__((ext_vector_type(2)));
 // Stores through ONE descriptor per workgroup: its base is the workgroup's first output row, its extent the workgroup's
 // block of rows (gfx950 range-checks the scalar offset together with the per-lane one: a one-row extent drops every
@@ -229,6 +262,9 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // directly and to T through the second-order term below — so what is left is third order: with
     // |d alpha| <= 1e-8 rad that is ~1e-15 rad and < 1e-25 s in fp64 (measured against the reference rays:
     // tests/test_gpu_lens_fermat.py).  fp32: 1e-5 rad is the type's resolution of alpha.
+    // (A looser fp32 tolerance for tables without the alpha output was measured — 1e-4 / 1e-3 rad: 2-7 % faster — and dropped:
+    // the mean error against the fp64 table grew from 3 to 29 / 233 fp32 ulps on coarse apertures close to the lens.)
+    constexpr bool T_ONLY = sizeof(R) == 4 && !WA;
     const R tol = sizeof(R) == 4 ? R(1e-5) : R(1e-8);
     // ... or when the step can no longer lower T noticeably (T is FLAT in alpha near the lens focus — the lens is
     // aplanatic — so alpha is ill-conditioned there while T is not): predicted gain g*step/2 below the type's resolution
@@ -246,6 +282,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     unsigned soff = 0;                                       // li * row_bytes
 
     unsigned long long rgp_bad = ~0ull;                      // lanes whose rgp is not usable (wave-uniform mask: the test is one scalar compare)
+    bool lite_ok = false;                                    // wave-uniform: the latest solve was ONE evaluation and every lane's step below tol
 
     // One solve from the start `alpha`.  Every lane holds a usable g' and the element has history (try_lite): ONE
     // evaluation of T and g, the Newton step with the previous element's g' (g' varies by ~1e-3 from one element to the
@@ -258,11 +295,17 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
             const R step = -g * rgp;
             const unsigned long long big = __builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT);
+            LDBG(2);
             if (!big) {
+                LDBG(3);
                 T_out = T + R(0.5) * g * step;               // T(a*) = T(a) - g^2 / (2 g')
+                lite_ok = true;
                 return alpha + step;
             }
         }
+        lite_ok = false;
+        LDBG(4);
+        if (try_lite && rgp_bad != 0) LDBG(5);
         R lo = a_lo, hi = a_hi;
         bool done = false;
         for (int trip = 0; trip < 80; ++trip) {              // wave-uniform trip count, ballot exit
@@ -287,17 +330,39 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     };
     // a mode-2 element: start extrapolated from the three previous solutions (n1 the newest; differences first: alpha*
     // varies slowly, so the weights — 3, -3, 1 on an even pitch — act on small numbers); the result replaces the oldest
+    R miss = R(0);                                           // minimiser minus extrapolated start of the latest step2 (T_ONLY)
     auto step2 = [&](int idx, R n1, R n2, R& n3) {
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;     // w2 = 1 - w1 - w3
         R T;
-        const R asol = solve(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), xa, za, true, T);
+        const R start = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
+        const R asol = solve(start, xa, za, true, T);
+        miss = asol - start;
         store_at<R>(rs_t, voff, soff, T);
         if (WA) store_at<R>(rs_a, voff, soff, asol);
         soff += row_bytes;
         n3 = asol;
     };
 
+    // fp32 tables only (T_ONLY): inside a run, when the verified element's extrapolated start turned out to be within tol of its
+    // minimiser in every lane (lite_ok), the next TWO elements take T at their extrapolated start and nothing else — no P', no g,
+    // no Newton step: stationarity makes T(start) exact to a small fraction of an fp32 ulp (lens_time_only), and the third
+    // element verifies again (its Newton step re-anchors alpha and measures how far the extrapolation had drifted).  Which
+    // elements verify is a function of the element's position in its run, i.e. of the whole table's blocks: shards reproduce it.
+    // The two unverified starts stay in the history the next starts are extrapolated from.  Left alone their errors feed
+    // back (weights 3, -3, 1): with a truncation error tau per extrapolation the starts are off by tau, 4 tau, 10 tau, then
+    // -10, -25, -44, ... tau — after a few triples the verified element's step exceeds tol and the whole wave iterates (measured:
+    // 27 % SLOWER than verifying everything).  The verified element measures its own 10 tau (`miss`), so the two entries are
+    // corrected by 0.1 and 0.4 of it, and the pattern tau, 4 tau, 10 tau repeats instead of growing.
+    bool hist_unverified = false;                            // al1, al2 of the next verified element are unverified starts
+    auto step2t = [&](int idx, R n1, R n2, R& n3) {
+        const R xa = rec[idx].xa, za = rec[idx].za;
+        const float w1 = rec[idx].w1, w3 = rec[idx].w3;
+        const R alpha = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
+        store_at<R>(rs_t, voff, soff, lens_time_only<R, POLY>(k, alpha, xa, za, xf, zf));
+        soff += row_bytes;
+        n3 = alpha;
+    };
     int li = 0;
     while (li < ne) {                                        // wave-uniform
         const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
@@ -307,10 +372,21 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
             for (int t = run / 3; t > 0; --t) {
                 step2(li, al1, al2, al3);                    // newest .. oldest = al3, al1, al2
-                step2(li + 1, al3, al1, al2);                //                    al2, al3, al1
-                step2(li + 2, al2, al3, al1);                //                    al1, al2, al3
+                if (T_ONLY && hist_unverified) { al1 += R(0.4) * miss; al2 += R(0.1) * miss; }
+                hist_unverified = false;
+                LDBG(0);
+                if (T_ONLY && lite_ok) {
+                    LDBG(1);
+                    step2t(li + 1, al3, al1, al2);
+                    step2t(li + 2, al2, al3, al1);
+                    hist_unverified = true;
+                } else {
+                    step2(li + 1, al3, al1, al2);            //                    al2, al3, al1
+                    step2(li + 2, al2, al3, al1);            //                    al1, al2, al3
+                }
                 li += 3;
             }
+            hist_unverified = false;
             for (int t = run % 3; t > 0; --t) {
                 step2(li, al1, al2, al3);
                 const R tn = al3; al3 = al2; al2 = al1; al1 = tn;
