@@ -309,6 +309,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         R lo = a_lo, hi = a_hi;
         bool done = false;
         for (int trip = 0; trip < 80; ++trip) {              // wave-uniform trip count, ballot exit
+            LDBG(6);
             lens_time<R, true, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
             if (g > R(0)) hi = alpha; else lo = alpha;      // T decreases left of the minimum
             rgp = rcp_r<R>(gp);
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // 27 % SLOWER than verifying everything).  The verified element measures its own 10 tau (`miss`), so the two entries are
     // corrected by 0.1 and 0.4 of it, and the pattern tau, 4 tau, 10 tau repeats instead of growing.
     bool hist_unverified = false;                            // al1, al2 of the next verified element are unverified starts
+    bool skip_next = false, skipped = false;                 // the next triple starts unverified as well / the latest one did
     auto step2t = [&](int idx, R n1, R n2, R& n3) {
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;
@@ -371,8 +373,19 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
             // registers without moves
             const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
             for (int t = run / 3; t > 0; --t) {
-                step2(li, al1, al2, al3);                    // newest .. oldest = al3, al1, al2
-                if (T_ONLY && hist_unverified) { al1 += R(0.4) * miss; al2 += R(0.1) * miss; }
+                if (T_ONLY && lite_ok && skip_next) {        // every other triple of a good streak does not verify at all
+                    step2t(li, al1, al2, al3);
+                    skip_next = false;
+                } else {
+                    step2(li, al1, al2, al3);                // newest .. oldest = al3, al1, al2
+                    // n unverified starts in a row are off by C(k+2, 3) tau (k = 1..n), the verified one after them by C(n+3, 3) tau = miss
+                    if (T_ONLY && hist_unverified) {
+                        al1 += (skipped ? R(35.0 / 56.0) : R(0.4)) * miss;
+                        al2 += (skipped ? R(20.0 / 56.0) : R(0.1)) * miss;
+                    }
+                    skip_next = true;
+                }
+                skipped = !skip_next;
                 hist_unverified = false;
                 LDBG(0);
                 if (T_ONLY && lite_ok) {
