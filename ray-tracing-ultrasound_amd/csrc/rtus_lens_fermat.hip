@@ -288,8 +288,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // evaluation of T and g, the Newton step with the previous element's g' (g' varies by ~1e-3 from one element to the
     // next; it only scales a step that is already below the stopping tolerance) and its second-order term — no
     // bracket, no g'', no loop.  If any lane's step is not small, or without try_lite: the safeguarded iteration.
+    R start_used = R(0);                                     // the (clamped) start of the latest solve
     auto solve = [&](R alpha, R xa, R za, bool try_lite, R& T_out) -> R {
         alpha = fmin(fmax(alpha, a_lo), a_hi);
+        start_used = alpha;
         R T, g, gp = R(0);
         if (try_lite && rgp_bad == 0) {                      // wave-uniform
             lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
@@ -336,9 +338,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;     // w2 = 1 - w1 - w3
         R T;
-        const R start = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
-        const R asol = solve(start, xa, za, true, T);
-        miss = asol - start;
+        const R asol = solve(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), xa, za, true, T);
+        miss = asol - start_used;
         store_at<R>(rs_t, voff, soff, T);
         if (WA) store_at<R>(rs_a, voff, soff, asol);
         soff += row_bytes;
