@@ -158,7 +158,7 @@ __device__ __forceinline__ void lens_time(const LensConst<R>& k, R alpha, R xa, 
 }
 
 // T(alpha) alone: no P', no g.  T is stationary in alpha at the ray (Fermat), so evaluated delta away from the minimiser it is off by
-// g' delta^2 / 2 — with g' ~ 1e-4 s/rad^2 and delta <= 1e-5 rad that is 5e-15 s, a thousandth of an fp32 ulp of T.
+// g' delta^2 / 2 — with g' ~ 1e-4 s/rad^2: 5e-15 s at delta = 1e-5 rad (fp32's tolerance), 5e-21 s at 1e-8 rad (fp64's).
 template <typename R, bool POLY>
 __device__ __forceinline__ R lens_time_only(const LensConst<R>& k, R alpha, R xa, R za, R xf, R zf)
 {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // tests/test_gpu_lens_fermat.py).  fp32: 1e-5 rad is the type's resolution of alpha.
     // (A looser fp32 tolerance for tables without the alpha output was measured — 1e-4 / 1e-3 rad: 2-7 % faster — and dropped:
     // the mean error against the fp64 table grew from 3 to 29 / 233 fp32 ulps on coarse apertures close to the lens.)
-    constexpr bool T_ONLY = sizeof(R) == 4 && !WA;
+    constexpr bool T_ONLY = !WA;
     const R tol = sizeof(R) == 4 ? R(1e-5) : R(1e-8);
     // ... or when the step can no longer lower T noticeably (T is FLAT in alpha near the lens focus — the lens is
     // aplanatic — so alpha is ill-conditioned there while T is not): predicted gain g*step/2 below the type's resolution
@@ -346,11 +346,12 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         n3 = asol;
     };
 
-    // fp32 tables only (T_ONLY): inside a run, when the verified element's extrapolated start turned out to be within tol of its
-    // minimiser in every lane (lite_ok), the next TWO elements take T at their extrapolated start and nothing else — no P', no g,
-    // no Newton step: stationarity makes T(start) exact to a small fraction of an fp32 ulp (lens_time_only), and the third
-    // element verifies again (its Newton step re-anchors alpha and measures how far the extrapolation had drifted).  Which
-    // elements verify is a function of the element's position in its run, i.e. of the whole table's blocks: shards reproduce it.
+    // Tables without the alpha output (T_ONLY): inside a run, when the verified element's extrapolated start turned out to be
+    // within tol of its minimiser in every lane (lite_ok), the next elements take T at their extrapolated start and nothing else —
+    // no P', no g, no Newton step: stationarity makes T(start) exact to g' tol^2 / 2 (fp32: 5e-15 s, a thousandth of an ulp of T;
+    // fp64, tol = 1e-8 rad: 5e-21 s, below the resolution of T), and a later element verifies again (its Newton step re-anchors
+    // alpha and measures how far the extrapolation had drifted).  Which elements verify is a function of the element's position
+    // in its run, i.e. of the whole table's blocks: shards reproduce it.
     // The two unverified starts stay in the history the next starts are extrapolated from.  Left alone their errors feed
     // back (weights 3, -3, 1): with a truncation error tau per extrapolation the starts are off by tau, 4 tau, 10 tau, then
     // -10, -25, -44, ... tau — after a few triples the verified element's step exceeds tol and the whole wave iterates (measured:
