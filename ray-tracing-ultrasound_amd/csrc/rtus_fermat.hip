@@ -433,10 +433,15 @@ int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_b
     int eb = (int)(wave_solves / (1024LL * 4));
     eb = eb < 1 ? 1 : (eb > 32 ? 32 : eb);
     if (wave_solves >= 1024LL * 16 * 64) eb = 64;
+    // fp32 tables are the curved-lens kernel's (the planar kernel is fp64 only): its block starts with three cold solves (~490 of
+    // a 64-row block's 3,600 VALU instructions once most rows need no Newton step), so twice the rows per block where that still
+    // leaves two full rounds of waves
+    const int eb_max = elem_bytes == 4 ? 128 : 64;
+    if (elem_bytes == 4 && wave_solves >= 1024LL * 16 * 128) eb = 128;
 #ifdef RTUS_EXP_EB                                          // experiment builds only (scripts/ab_planar.py)
-    eb = RTUS_EXP_EB < 1 ? 1 : (RTUS_EXP_EB > 64 ? 64 : RTUS_EXP_EB);
+    eb = RTUS_EXP_EB < 1 ? 1 : (RTUS_EXP_EB > eb_max ? eb_max : RTUS_EXP_EB);
 #endif
-    while ((n_rows_total + eb - 1) / eb > 65535 && eb < 64) ++eb;   // grid.y limit (eb <= 64: one LDS record per element)
+    while ((n_rows_total + eb - 1) / eb > 65535 && eb < eb_max) ++eb;   // grid.y limit (eb <= 64 / 128: one LDS record per element)
     if ((unsigned long long)eb * (unsigned long long)n_f * (unsigned)elem_bytes >= 0xffffffffull)   // row offsets inside a block are 32-bit
         eb = (int)(0xffffffffull / ((unsigned long long)n_f * (unsigned)elem_bytes));
     return eb;

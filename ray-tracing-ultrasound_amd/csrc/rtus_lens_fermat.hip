@@ -221,21 +221,23 @@ template <typename R> struct __attribute__((aligned(16))) LensRec {
 template <typename R, bool POLY, bool WA>
 __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> a)
 {
-    __shared__ LensRec<R> rec[64];
+    __shared__ LensRec<R> rec[128];                          // eb <= 128 (fp32 tables; 64 for fp64: rtus_rows_per_block)
+    __shared__ unsigned long long m2s[2];                    // per header wave: which of its elements extrapolate (mode 2)
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const R xf = a.xf[f], zf = a.zf[f];
     const int gb = a.row0 / a.eb + blockIdx.y;              // the workgroup's block of the whole table
     const int e0 = max(gb * a.eb - a.row0, 0), ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const int el = min(e0 + lane, a.n_e - 1);
+    LensRec<R> r;
+    const int idx = threadIdx.x, lane = threadIdx.x & 63;    // header: thread idx works out the record of the block's element idx
+    if (idx < 128) {
+        const int el = min(e0 + idx, a.n_e - 1);
         const R xe_v = a.xe[el], ze_v = a.ze[el];
         const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0);
         const R x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3];
         const R z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3];            // all loads issued together
-        const bool s1 = (lane >= 1) & (z1 == ze_v), s2 = s1 & (lane >= 2) & (z2 == ze_v), s3 = s2 & (lane >= 3) & (z3 == ze_v);
+        const bool s1 = (idx >= 1) & (z1 == ze_v), s2 = s1 & (idx >= 2) & (z2 == ze_v), s3 = s2 & (idx >= 3) & (z3 == ze_v);
         const int hist = s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0));
         const float d12 = (float)(x1 - x2), d13 = (float)(x1 - x3), d23 = (float)(x2 - x3);
         const float t1 = (float)(xe_v - x1), t2 = (float)(xe_v - x2), t3 = (float)(xe_v - x3);
@@ -244,15 +246,22 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         const float r12 = __builtin_amdgcn_rcpf(d12);
         const float q1 = t2 * t3 * __builtin_amdgcn_rcpf(d12 * d13);
         const float q3 = t1 * t2 * __builtin_amdgcn_rcpf(d13 * d23);
-        LensRec<R> r;
         r.xa = xe_v; r.za = ze_v;
         r.w1 = quad ? q1 : (lin ? t2 * r12 : 0.0f);
         r.w3 = quad ? q3 : 0.0f;
         r.mode = lin ? 2 : (hist >= 1 ? 1 : 0);
-        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(r.mode == 2 && lane < ne);
-        const unsigned long long rest = ~(m2 >> lane);
-        r.run = (r.mode == 2 && lane < ne) ? (rest ? __ffsll((long long)rest) - 1 : 64 - lane) : 0;
-        rec[lane] = r;
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(r.mode == 2 && idx < ne);
+        if (lane == 0) m2s[idx >> 6] = m2;
+    }
+    __syncthreads();
+    if (idx < 128) {
+        // the run of mode-2 elements from this one on: the rest of this wave's 64 elements, continued into the second wave's
+        const unsigned long long mine = m2s[idx >> 6], next = idx < 64 ? m2s[1] : 0ull;
+        const unsigned long long rest = ~(mine >> lane);
+        const int here = rest ? __ffsll((long long)rest) - 1 : 64 - lane;
+        const int more = (here == 64 - lane && idx < 64) ? (~next ? __ffsll((long long)~next) - 1 : 64) : 0;   // (the shift fills `rest` with ones from bit 64 - lane on)
+        r.run = (r.mode == 2 && idx < ne) ? here + more : 0;
+        rec[idx] = r;
     }
     __syncthreads();
     const LensConst<R> k = lens_const<R>(a);
