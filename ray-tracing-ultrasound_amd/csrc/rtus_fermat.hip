@@ -63,6 +63,18 @@ __device__ __forceinline__ double rsqrt_refine(double a, double y)
     return fma(y * e, 0.5, y);
 }
 
+#ifdef RTUS_EXP_COUNT
+static __device__ unsigned long long planar_dbg[8];
+extern "C" int rtus_dbg_read_planar(unsigned long long* out)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(planar_dbg), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(planar_dbg), z, sizeof(z));
+    return 0;
+}
+#endif
+
 // One element's record in LDS: every lane of the workgroup reads the same address (broadcast, no VALU slot —
 // a v_readlane costs 4.2 cycles and leaves its value in an SGPR, which halves the rate of every fp32 op reading it).
 struct __attribute__((aligned(16))) ElemRec {
@@ -201,6 +213,19 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
         // the cubic extrapolation is nearly always within tau of the root: one evaluation, no clamp, no select
         q = fabsf(fmaf(R.w1, h1, fmaf(R.w2, h2, fmaf(R.w3, h3, R.w4 * h4))));
         eval(q);
+#ifdef RTUS_EXP_COUNT   // experiment builds only (scripts/exp_planar_miss.py): how far the cubic predictor lands from the root
+        if (live && L.tau < 1.0f) {
+            const float rel = fabsf(dq) / q;
+            atomicAdd(&planar_dbg[0], 1ull);
+            if (rel > 1e-7f) atomicAdd(&planar_dbg[1], 1ull);
+            if (rel > 3e-7f) atomicAdd(&planar_dbg[2], 1ull);
+            if (rel > 1e-6f) atomicAdd(&planar_dbg[3], 1ull);
+            if (rel > 3e-6f) atomicAdd(&planar_dbg[4], 1ull);
+            if (rel > 1e-5f) atomicAdd(&planar_dbg[5], 1ull);
+            if (rel > 1e-4f) atomicAdd(&planar_dbg[6], 1ull);
+            atomicMax((unsigned long long*)&planar_dbg[7], (unsigned long long)__float_as_uint(rel));
+        }
+#endif
         const bool big = fabsf(dq) > L.tau * q;
         if (__builtin_amdgcn_ballot_w64(big)) {             // rare (wave-uniform): some lane wants a second evaluation
             asm volatile("" : "+v"(q));                     // keeps this block a branch (nothing of it is speculated)
