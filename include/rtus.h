@@ -118,7 +118,12 @@ int rtus_selftest(const rtus_lens *lens, int n_rays, long long n_math, unsigned 
  * the reference's driver traces 210 geometries over one grid (main_rt.py:464-482). */
 #define RTUS_POLYLINE_READY 0x8u
 
-/* Device scratch of one call (polyline, tangents, bounding boxes and their depth-first records): 64-byte aligned
+/* rtus_shoot (host buffers) keeps the lens polyline of its previous call on the device in a per-device arena and rebuilds it
+ * only when alpha's VALUES or the lens constants differ from that call's (compared byte for byte) — the reference's script
+ * calls shoot_rays 210 times over one grid (main_rt.py:464-482).  Invisible apart from the time it saves; rtus_release()
+ * drops it.
+ *
+ * Device scratch of one call (polyline, tangents, bounding boxes and their depth-first records): 64-byte aligned
  * (hipMalloc gives 256), rebuilt by every call, not shared between calls that may run concurrently. */
 size_t rtus_shoot_workspace_bytes(int n_rays);
 

@@ -62,3 +62,40 @@ def test_polyline_ready_keeps_the_bits(rtus):
     o1 = sp.run(t(s["geoms"][[3, 50]]), xa, za, alpha, zf)["out8"].clone()
     o2 = sp.run(t(s["geoms"][[3, 50]]), xa, za, alpha, zf, polyline_ready=True)["out8"]
     assert torch.equal(o1.view(torch.uint8), o2.view(torch.uint8))
+
+
+def test_host_calls_keep_the_polyline_only_while_alpha_and_lens_are_unchanged(rtus):
+    """rtus_shoot (host buffers) keeps the lens polyline of the previous call in its arena and skips the polyline launch when the
+    launch-angle grid and the lens constants are byte for byte the same — the reference's calling pattern, 210 shoot_rays over one
+    grid.  Whatever changes between calls (geometry, transmit point, the grid's VALUES behind the same array object, the lens,
+    the ray count), every call must give the bits of a fresh library state (rtus_release) and stay on the oracle."""
+    from oracle import cport
+    rng = np.random.default_rng(21)
+    n = 905
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    zf = np.full(n, D_PLANE)
+
+    def call(al, p, x_tx, fresh=False):
+        if fresh:
+            assert rtus.lib().rtus_release(-1) == 0
+        r = rtus.shoot_rays(x_tx, p.d, np.full(al.size, p.d), al, plot=False, params=p)
+        return np.stack([r[k] for k in rtus.KEYS])
+
+    p0 = rtus.Params(r_outer=0.037, pipe_offset=0.0038)
+    steps = [(alpha, p0, 0.0), (alpha, rtus.Params(r_outer=0.05, pipe_offset=-0.002), 0.0),          # other geometry, same grid
+             (alpha, p0, 0.0081)]                                                                      # other transmit point
+    a2 = alpha.copy()
+    steps.append((a2, p0, 0.0))                                                                        # another array, same values
+    for al, p, x in steps:
+        assert np.array_equal(call(al, p, x), call(al, p, x, fresh=True), equal_nan=True)
+    a2[100:200] += 1e-4                                                                                # same array object, other values
+    got = call(a2, p0, 0.0)
+    assert np.array_equal(got, call(a2, p0, 0.0, fresh=True), equal_nan=True)
+    ref, _ = cport.shoot(0.0, p0.d, np.full(n, p0.d), a2, 0.037, 0.0038)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) < 1e-12
+    p_lens = rtus.Params(r_outer=0.037, pipe_offset=0.0038, c1=6300.0)                                 # other lens constants
+    assert np.array_equal(call(a2, p_lens, 0.0), call(a2, p_lens, 0.0, fresh=True), equal_nan=True)
+    assert not np.array_equal(call(a2, p_lens, 0.0), got, equal_nan=True)
+    short = np.linspace(-0.5, 0.5, 300)                                                                # other ray count, then back
+    assert np.array_equal(call(short, p0, 0.0), call(short, p0, 0.0, fresh=True), equal_nan=True)
+    assert np.array_equal(call(alpha, p0, 0.0), call(alpha, p0, 0.0, fresh=True), equal_nan=True)
