@@ -168,11 +168,37 @@ struct Session {                       // one host-buffer call on one device
     }
     template <class T> void download(T* h, const T* d, size_t count)
     {
-        if (h) down[n_down++] = {(void*)h, (size_t)((const char*)d - (const char*)a->dev), count * sizeof(T)};
+        if (h && !((const char*)d >= a->pin && (const char*)d < a->pin + 2 * kPinBytes))      // (direct outputs are already registered)
+            down[n_down++] = {(void*)h, (size_t)((const char*)d - (const char*)a->dev), count * sizeof(T)};
+    }
+    // Small results written by the kernel STRAIGHT into the page-locked buffer (it is device-visible): no device-to-host copy
+    // command behind the kernel (9 of a 32-us call) — the stores cross PCIe while the kernel runs.  (The same for the inputs —
+    // the kernel reading them from the page-locked buffer instead of one small host-to-device copy — was measured: no gain.)  `direct_budget` = bytes of
+    // results the call will ask for; call direct_ok() once with it, then take_out() per result.
+    bool direct = false;
+    size_t direct_off = 0;
+    Xfer direct_down[8];
+    int n_direct = 0;
+    void direct_ok(size_t total_result_bytes) { direct = total_result_bytes + 8 * 256 <= kPinBytes / 4; }
+    template <class T> T* take_out(T* host, size_t count)            // nullptr when the caller does not want this result
+    {
+        if (!host || !count) return nullptr;
+        if (!direct) return take<T>(count);
+        T* p = (T*)(a->pin + kPinBytes + direct_off);
+        direct_down[n_direct++] = {(void*)host, direct_off, count * sizeof(T)};
+        direct_off += al256(count * sizeof(T));
+        return p;
     }
     // results back + synchronise: one device-to-host copy through the page-locked buffer when they are small
     hipError_t finish()
     {
+        if (n_direct) {                                              // results are in the page-locked buffer once the stream has drained
+            const hipError_t e = hipStreamSynchronize(a->stream);
+            if (e != hipSuccess) return e;
+            drained = true;
+            for (int i = 0; i < n_direct; ++i) memcpy(direct_down[i].host, a->pin + kPinBytes + direct_down[i].off, direct_down[i].bytes);
+            if (!n_down) return hipSuccess;
+        }
         if (n_down) {
             size_t lo = down[0].off, hi = 0;
             for (int i = 0; i < n_down; ++i) { lo = down[i].off < lo ? down[i].off : lo; hi = down[i].off + down[i].bytes > hi ? down[i].off + down[i].bytes : hi; }
@@ -354,11 +380,12 @@ int rtus_shoot(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     if (!keep) S.upload(al, alpha, n);
     S.upload(zf, z_f, n);
     void* ws = A.poly_ws;
-    double* o8 = out8 ? S.take<double>(8 * rn) : nullptr;
-    double* t4 = tof4 ? S.take<double>(4 * rn) : nullptr;
-    double* tt = tof ? S.take<double>(rn) : nullptr;
-    double* lx = land_x ? S.take<double>(rn) : nullptr;
-    uint8_t* sb = status ? S.take<uint8_t>(rn) : nullptr;
+    S.direct_ok((out8 ? 64 * rn : 0) + (tof4 ? 32 * rn : 0) + (tof ? 8 * rn : 0) + (land_x ? 8 * rn : 0) + (status ? rn : 0));
+    double* o8 = S.take_out(out8, 8 * rn);
+    double* t4 = S.take_out(tof4, 4 * rn);
+    double* tt = S.take_out(tof, rn);
+    double* lx = S.take_out(land_x, rn);
+    uint8_t* sb = S.take_out(status, rn);
     HIP_TRY(S.flush());
     LAUNCH_TRY(rtus_launch_shoot(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, o8, t4, tt, lx, sb, ws,
                                  (flags & ~RTUS_POLYLINE_READY) | (keep ? RTUS_POLYLINE_READY : 0u), S.a->stream));
