@@ -458,11 +458,13 @@ int rtus_solve(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     S.upload(al, alpha, n_rays);
     S.upload(rx, x_rx, n_rx);
     void* ws = S.take<char>(wsb);
-    double* dt = S.take<double>(tot);
-    double* da = alpha_root ? S.take<double>(tot) : nullptr;
-    double* dta = tt_all ? S.take<double>(tot * RTUS_MAX_ROOTS) : nullptr;
-    double* daa = alpha_all ? S.take<double>(tot * RTUS_MAX_ROOTS) : nullptr;
-    uint8_t* dn = n_roots ? S.take<uint8_t>(tot) : nullptr;
+    S.direct_ok(8 * tot + (alpha_root ? 8 * tot : 0) + (tt_all ? 8 * tot * RTUS_MAX_ROOTS : 0) + (alpha_all ? 8 * tot * RTUS_MAX_ROOTS : 0) +
+                (n_roots ? tot : 0));
+    double* dt = S.take_out(tt, tot);
+    double* da = S.take_out(alpha_root, tot);
+    double* dta = S.take_out(tt_all, tot * RTUS_MAX_ROOTS);
+    double* daa = S.take_out(alpha_all, tot * RTUS_MAX_ROOTS);
+    uint8_t* dn = S.take_out(n_roots, tot);
     HIP_TRY(S.flush());
     LAUNCH_TRY(rtus_launch_solve(*lens, g, n_geom, xa, za, n_tx, al, n_rays, rx, n_rx, z_land, dt, da, dta, daa, dn, ws,
                               flags & ~RTUS_POLYLINE_READY, S.a->stream));
@@ -608,11 +610,12 @@ int rtus_sweep(const rtus_lens* lens, const double* geoms, int n_geom, const dou
     S.upload(zf, z_f, n);
     S.upload(rx, x_rx, n_rx);
     void* ws = S.take<char>(wsb);
-    int32_t* fr = S.take<int32_t>(re);
-    uint8_t* hb = hit ? S.take<uint8_t>(re) : nullptr;
-    double* th = tof_hit ? S.take<double>(re) : nullptr;
-    double* tt = tof ? S.take<double>(rn) : nullptr;
-    double* lx = land_x ? S.take<double>(rn) : nullptr;
+    S.direct_ok(4 * re + (hit ? re : 0) + (tof_hit ? 8 * re : 0) + (tof ? 8 * rn : 0) + (land_x ? 8 * rn : 0));
+    int32_t* fr = S.take_out(first_ray, re);
+    uint8_t* hb = S.take_out(hit, re);
+    double* th = S.take_out(tof_hit, re);
+    double* tt = S.take_out(tof, rn);
+    double* lx = S.take_out(land_x, rn);
     HIP_TRY(S.flush());
     LAUNCH_TRY(rtus_launch_sweep(*lens, g, n_geom, xa, za, n_tx, al, zf, n_rays, rx, n_rx, atol, rtol, fr, hb, th, tt, lx, ws,
                               flags & ~RTUS_POLYLINE_READY, S.a->stream));
