@@ -386,6 +386,8 @@ def main(argv=None):
         def reassemble():
             pass
 
+        gather_step = gather_end = gather_after = False     # independent rows per rank, no table to reassemble
+
     # ---- warm-up ----------------------------------------------------------------------------------
     for s in range(args.warmup):
         step(s)
@@ -450,7 +452,7 @@ def main(argv=None):
                      "fp64 results, default tier: Newton PRE-iteration on the fp32 pipe, the result from an fp64 evaluation + Fermat "
                      "expansion (measured max |dt| vs the long-double oracle: see `accuracy`)")
                 if wl in PLANAR else "fp64, reference-compatible arithmetic"),
-            "sharding": f"tx-element rows x{world}" + (", RCCL all-gather every step (overlapped)" if gather_step else
+            "sharding": (f"tx-element rows x{world}" if m is not None else f"{world} rank(s), each its own (geometry, tx) rows: no exchange") + (", RCCL all-gather every step (overlapped)" if gather_step else
                                                        ", RCCL all-gather of the final matrix inside the timed region" if gather_end else
                                                        ", collective-free timed region; RCCL all-gather of the table timed right after" if gather_after else ""),
             "launch": ((f"hipGraph replay of K launches on {args.streams} stream(s)" if args.streams > 1 else "hipGraph replay of K launches") +

@@ -134,6 +134,14 @@ def test_bench_weak_scaled_planar_and_gather_modes():
     assert "every step" in d["config"]["sharding"] and d["config"]["launch"] == "eager launches"
 
 
+def test_bench_reference_sweep_workload_two_ranks():
+    """--workload ref_sweep at N = 2: every rank runs the fused trace + matcher entry on its own copy of the sweep (weak scaling, no
+    collective), rank 0 prints the line."""
+    d = _run_bench_two_ranks(["--workload", "ref_sweep", "--no-extra", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "true>" in d["roofline"]["kernel"] and "reference sweep" in d["config"]["workload"] and "no exchange" in d["config"]["sharding"]
+
+
 def _tfm_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
