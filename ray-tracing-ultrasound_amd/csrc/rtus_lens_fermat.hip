@@ -366,8 +366,8 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // -10, -25, -44, ... tau — after a few triples the verified element's step exceeds tol and the whole wave iterates (measured:
     // 27 % SLOWER than verifying everything).  The verified element measures its own 10 tau (`miss`), so the two entries are
     // corrected by 0.1 and 0.4 of it, and the pattern tau, 4 tau, 10 tau repeats instead of growing.
-    bool hist_unverified = false;                            // al1, al2 of the next verified element are unverified starts
-    bool skip_next = false, skipped = false;                 // the next triple starts unverified as well / the latest one did
+    int nun = 0;                                             // unverified starts in a row since the latest verified element (wave-uniform)
+    bool skip_next = false;                                  // the next triple starts unverified as well
     auto step2t = [&](int idx, R n1, R n2, R& n3) {
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;
@@ -387,30 +387,32 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
                 if (T_ONLY && lite_ok && skip_next) {        // every other triple of a good streak does not verify at all
                     step2t(li, al1, al2, al3);
                     skip_next = false;
+                    nun += 1;
                 } else {
                     step2(li, al1, al2, al3);                // newest .. oldest = al3, al1, al2
-                    // n unverified starts in a row are off by C(k+2, 3) tau (k = 1..n), the verified one after them by C(n+3, 3) tau = miss
-                    if (T_ONLY && hist_unverified) {
-                        al1 += (skipped ? R(35.0 / 56.0) : R(0.4)) * miss;
-                        al2 += (skipped ? R(20.0 / 56.0) : R(0.1)) * miss;
+                    // n unverified starts in a row are off by C(k+2, 3) tau (k = 1..n) and the verified one after them by C(n+3, 3) tau
+                    // = miss: the two still in the history (k = n, n - 1) are corrected by their share of it (n = 2, 3 or 5)
+                    if (T_ONLY && nun > 0) {
+                        al1 += (nun == 2 ? R(0.4) : (nun == 3 ? R(0.5) : R(35.0 / 56.0))) * miss;
+                        al2 += (nun == 2 ? R(0.1) : (nun == 3 ? R(0.2) : R(20.0 / 56.0))) * miss;
                     }
                     skip_next = true;
+                    nun = 0;
                 }
-                skipped = !skip_next;
-                hist_unverified = false;
                 LDBG(0);
                 if (T_ONLY && lite_ok) {
                     LDBG(1);
                     step2t(li + 1, al3, al1, al2);
                     step2t(li + 2, al2, al3, al1);
-                    hist_unverified = true;
+                    nun += 2;
                 } else {
                     step2(li + 1, al3, al1, al2);            //                    al2, al3, al1
                     step2(li + 2, al2, al3, al1);            //                    al1, al2, al3
+                    nun = 0;
                 }
                 li += 3;
             }
-            hist_unverified = false;
+            nun = 0;
             for (int t = run % 3; t > 0; --t) {
                 step2(li, al1, al2, al3);
                 const R tn = al3; al3 = al2; al2 = al1; al1 = tn;
