@@ -444,7 +444,7 @@ def main(argv=None):
                                      (f" ({units_per_step // n_f if m is not None else 0} tx rows per GPU)" if m is not None else "")),
             "solves_per_step_per_gpu": units_per_step,
             "solves_per_step_all_gpus": total_units_per_step,
-            "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64)"}.get(
+            "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64 where both follow the same ray path; DESIGN section 4 on minima at the end of the search interval)"}.get(
                 wl, ("fp64 results, tier RTUS_TT_TAUP_TAIL: Newton PRE-iteration on the fp32 pipe, the travel time from the tau-p form "
                      "p X + sum (h/c) cos(theta) in fp64 (stationary in p) + its second-order term from the fp32 residual — <= 6e-11 "
                      "relative by construction, measured max |dt| vs the long-double oracle: see `accuracy`; the library's default tier "
