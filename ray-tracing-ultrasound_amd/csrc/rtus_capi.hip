@@ -173,8 +173,8 @@ struct Session {                       // one host-buffer call on one device
     }
     // Small results written by the kernel STRAIGHT into the page-locked buffer (it is device-visible): no device-to-host copy
     // command behind the kernel (9 of a 32-us call) — the stores cross PCIe while the kernel runs.  (The same for the inputs —
-    // the kernel reading them from the page-locked buffer instead of one small host-to-device copy — was measured: no gain.)  `direct_budget` = bytes of
-    // results the call will ask for; call direct_ok() once with it, then take_out() per result.
+    // the kernel reading them from the page-locked buffer instead of one small host-to-device copy — was measured: no gain.)
+    // Use: direct_ok(bytes of all results the call will ask for) once, then take_out() per result instead of take() + download().
     bool direct = false;
     size_t direct_off = 0;
     Xfer direct_down[8];
