@@ -43,6 +43,7 @@ template <typename R> struct LensFermatArgs {
     int n_e, n_f, eb;
     int row0;                // index of xe[0] in the whole table (row shards: workgroups stay aligned to the table's blocks, see rtus_fermat.hip)
     int poly_trig;           // 1: [a_lo, a_hi] lies inside [-1, 1] rad -> sin/cos by polynomial, no range reduction
+    R gp_min, gp_dx;         // a lane whose g' at its minimum is below gp_min + gp_dx |x_e - x_full| may have a second minimum (kernel comment)
 };
 
 template <typename R> __device__ __forceinline__ R rsqrt_r(R v);
@@ -219,7 +220,7 @@ template <typename R> struct __attribute__((aligned(16))) LensRec {
 // POLY: sin / cos by polynomial (search interval inside +-1 rad); WA: the minimising alpha is written too.  Both are
 // launch-time facts: as template parameters they leave no wave-uniform branches in the element loop.
 template <typename R, bool POLY, bool WA>
-__global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs<R> a)
+__global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_lens_kernel(LensFermatArgs<R> a)
 {
     __shared__ LensRec<R> rec[128];                          // eb <= 128 (fp32 tables; 64 for fp64: rtus_rows_per_block)
     __shared__ unsigned long long m2s[2];                    // per header wave: which of its elements extrapolate (mode 2)
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     // aplanatic — so alpha is ill-conditioned there while T is not): predicted gain g*step/2 below the type's resolution
     const R tolT = sizeof(R) == 4 ? R(2e-12) : R(1e-21);
 
-    R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements
+    R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements (al1 the newest)
     R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation (usable if that solve
                                                             // ended at an interior minimum: rgp_bad below)
+    R x_full = R(0);                                        // position of the element that evaluation belonged to (wave-uniform)
     const unsigned row_bytes = (unsigned)a.n_f * (unsigned)sizeof(R);
     const unsigned blk_bytes = (unsigned)ne * row_bytes;     // < 2^32: the launcher sizes eb for it
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(a.tt + (size_t)e0 * a.n_f, 0, blk_bytes, 0x00020000);
@@ -291,84 +293,59 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
     unsigned soff = 0;                                       // li * row_bytes
 
     unsigned long long rgp_bad = ~0ull;                      // lanes whose rgp is not usable (wave-uniform mask: the test is one scalar compare)
-    bool lite_ok = false;                                    // wave-uniform: the latest solve was ONE evaluation and every lane's step below tol
 
-    // One solve from the start `alpha`.  Every lane holds a usable g' and the element has history (try_lite): ONE
-    // evaluation of T and g, the Newton step with the previous element's g' (g' varies by ~1e-3 from one element to the
-    // next; it only scales a step that is already below the stopping tolerance) and its second-order term — no
-    // bracket, no g'', no loop.  If any lane's step is not small, or without try_lite: the safeguarded iteration.
-    R start_used = R(0);                                     // the (clamped) start of the latest solve
-    auto solve = [&](R alpha, R xa, R za, bool try_lite, R& T_out) -> R {
-        alpha = fmin(fmax(alpha, a_lo), a_hi);
-        start_used = alpha;
-        R T, g, gp = R(0);
-        if (try_lite && rgp_bad == 0) {                      // wave-uniform
-            lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
-            const R step = -g * rgp;
-            const unsigned long long big = __builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT);
-            LDBG(2);
-            if (!big) {
-                LDBG(3);
-                T_out = T + R(0.5) * g * step;               // T(a*) = T(a) - g^2 / (2 g')
-                lite_ok = true;
-                return alpha + step;
-            }
-        }
-        lite_ok = false;
-        LDBG(4);
-        if (try_lite && rgp_bad != 0) LDBG(5);
-        R lo = a_lo, hi = a_hi;
-        bool done = false;
-        for (int trip = 0; trip < 80; ++trip) {              // wave-uniform trip count, ballot exit
-            LDBG(6);
-            lens_time<R, true, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
-            if (g > R(0)) hi = alpha; else lo = alpha;      // T decreases left of the minimum
-            rgp = rcp_r<R>(gp);
-            R step = -g * rgp;
-            R next = alpha + step;
-            const bool bad = !(gp > R(0)) || !(next > lo) || !(next < hi);
-            if (bad) { next = R(0.5) * (lo + hi); step = next - alpha; }
-            const bool go = fabs(step) > tol && fabs(g * step) > tolT && !done;
-            if (!__builtin_amdgcn_ballot_w64(go)) break;
-            if (go) alpha = next; else done = true;         // a finished lane keeps its alpha (T, g belong to it)
-        }
-        // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g')
-        // (only where Newton converged in the interior; a minimum pinned at an interval end keeps T(alpha))
-        const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
-        rgp_bad = __builtin_amdgcn_ballot_w64(!interior);
-        const R dal = interior ? -g * rgp : R(0);
-        T_out = interior ? T + R(0.5) * g * dal : T;
-        return alpha + dal;
-    };
-    // a mode-2 element: start extrapolated from the three previous solutions (n1 the newest; differences first: alpha*
-    // varies slowly, so the weights — 3, -3, 1 on an even pitch — act on small numbers); the result replaces the oldest
-    R miss = R(0);                                           // minimiser minus extrapolated start of the latest step2 (T_ONLY)
-    auto step2 = [&](int idx, R n1, R n2, R& n3) {
+    // WHEN THE MINIMUM FOLLOWED FROM ELEMENT TO ELEMENT MAY NOT BE THE LEAST TIME.  The lens is aplanatic: for a target at its
+    // focus T(alpha) is constant, around the focus it is nearly flat, and an off-axis element can then have TWO local minima (an
+    // interior ray and an end of the interval, or both ends — beyond the focus T has its maximum in the middle).  A continuation
+    // follows one of them; the table entry is the lesser (Fermat).  Measured on the CPU over the water below the reference lens
+    // (elements within +-20 mm, 4,001 samples of alpha per pair): wherever a pair has more than one local
+    // minimum, g' at every INTERIOR one is <= 3.7e-6 s/rad^2, against >= 3e-5 on tables away from the focus (BASELINE configs[3]:
+    // 2.9e-5 ... 2.3e-4).  So a lane is SUSPECT when its minimum is pinned at an end of the interval or its latest g' is below
+    // gp_min (= 1.5e-5 for the reference lens: four times the bound) + gp_dx |x_e - x_full| (g' at the followed minimum moves by
+    // <= 1.2e-3 s/rad^2 per metre of element position; the lite steps below do not refresh it); a suspect wave leaves the fast rows
+    // for the generic step, which looks at the whole interval (`scan`).  Not suspect => one minimum => the continuation is right.
+    R gp_min = a.gp_min, gp_dx = a.gp_dx;
+    if (sizeof(R) == 4) asm("" : "+v"(gp_min), "+v"(gp_dx));
+
+    // ---- the fast rows: elements of a run (mode 2), every lane with a usable, unsuspicious g' ----------------------------------
+    // ONE evaluation of T and g at the start extrapolated from the three previous solutions (n1 the newest; differences first:
+    // alpha* varies slowly, so the weights — 3, -3, 1 on an even pitch — act on small numbers), the Newton step with the g' of the
+    // lane's latest full evaluation (g' varies by ~1e-3 from one element to the next; it only scales a step that is already below
+    // the stopping tolerance) and its second-order term — no bracket, no g'', no loop.  Returns false — nothing stored, the
+    // history untouched — when some lane's step is not small or some lane has become suspect: the generic step takes over.
+    R miss = R(0);                                           // minimiser minus extrapolated start of the latest lite step (T_ONLY)
+    auto lite = [&](int idx, R n1, R n2, R& n3) -> bool {
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;     // w2 = 1 - w1 - w3
-        R T;
-        const R asol = solve(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), xa, za, true, T);
-        miss = asol - start_used;
-        store_at<R>(rs_t, voff, soff, T);
-        if (WA) store_at<R>(rs_a, voff, soff, asol);
+        const R alpha = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
+        R T, g, gp = R(0);
+        lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
+        const R step = -g * rgp;
+        const unsigned long long flat = __builtin_amdgcn_ballot_w64(rgp * fma(gp_dx, fabs(xa - x_full), gp_min) > R(1));
+        const unsigned long long big = (__builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT)) | flat;
+        LDBG(2);
+        if (flat) LDBG(7);
+        if (big) return false;
+        LDBG(3);
+        miss = step;
+        store_at<R>(rs_t, voff, soff, T + R(0.5) * g * step);    // T(a*) = T(a) - g^2 / (2 g')
+        if (WA) store_at<R>(rs_a, voff, soff, alpha + step);
         soff += row_bytes;
-        n3 = asol;
+        n3 = alpha + step;
+        return true;
     };
-
-    // Tables without the alpha output (T_ONLY): inside a run, when the verified element's extrapolated start turned out to be
-    // within tol of its minimiser in every lane (lite_ok), the next elements take T at their extrapolated start and nothing else —
+    // Tables without the alpha output (T_ONLY): inside a run, after an element whose lite step succeeded (every lane's
+    // extrapolated start within tol of its minimiser), the next elements take T at their extrapolated start and nothing else —
     // no P', no g, no Newton step: stationarity makes T(start) exact to g' tol^2 / 2 (fp32: 5e-15 s, a thousandth of an ulp of T;
     // fp64, tol = 1e-8 rad: 5e-21 s, below the resolution of T), and a later element verifies again (its Newton step re-anchors
-    // alpha and measures how far the extrapolation had drifted).  Which elements verify is a function of the element's position
-    // in its run, i.e. of the whole table's blocks: shards reproduce it.
-    // The two unverified starts stay in the history the next starts are extrapolated from.  Left alone their errors feed
+    // alpha and measures how far the extrapolation had drifted).  Which elements verify is a function of the table (the element's
+    // position in its run and where lite steps failed), never of the launch: shards reproduce it.
+    // The unverified starts stay in the history the next starts are extrapolated from.  Left alone their errors feed
     // back (weights 3, -3, 1): with a truncation error tau per extrapolation the starts are off by tau, 4 tau, 10 tau, then
     // -10, -25, -44, ... tau — after a few triples the verified element's step exceeds tol and the whole wave iterates (measured:
     // 27 % SLOWER than verifying everything).  The verified element measures its own 10 tau (`miss`), so the two entries are
     // corrected by 0.1 and 0.4 of it, and the pattern tau, 4 tau, 10 tau repeats instead of growing.
-    int nun = 0;                                             // unverified starts in a row since the latest verified element (wave-uniform)
-    bool skip_next = false;                                  // the next triple starts unverified as well
-    auto step2t = [&](int idx, R n1, R n2, R& n3) {
+    auto tonly = [&](int idx, R n1, R n2, R& n3) {
         const R xa = rec[idx].xa, za = rec[idx].za;
         const float w1 = rec[idx].w1, w3 = rec[idx].w3;
         const R alpha = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
@@ -376,20 +353,145 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
         soff += row_bytes;
         n3 = alpha;
     };
+
+    // ---- the generic step: any element, one at a time ----------------------------------------------------------------------------
+    R xa_cur = R(0), za_cur = R(0);                          // the element the generic step is working on
+    int nun = 0;                                             // unverified starts (T-only rows) in a row since the latest verified element (wave-uniform)
+    // safeguarded Newton on g inside the bracket [lo, hi] (kept by the sign of g: T decreases left of a minimum), bisection
+    // whenever Newton leaves it; wave-uniform trip count, ballot exit.  On return T, g, gp belong to alpha.
+    auto iterate = [&](R& alpha, R lo, R hi, R& T, R& g, R& gp) {
+        bool done = false;
+        for (int trip = 0; trip < 80; ++trip) {
+            LDBG(6);
+            lens_time<R, true, POLY>(k, alpha, xa_cur, za_cur, xf, zf, T, g, gp);
+            if (g > R(0)) hi = alpha; else lo = alpha;
+            R step = -g * rcp_r<R>(gp);
+            R next = alpha + step;
+            const bool bad = !(gp > R(0)) || !(next > lo) || !(next < hi);
+            if (bad) { next = R(0.5) * (lo + hi); step = next - alpha; }
+            const bool go = fabs(step) > tol && fabs(g * step) > tolT && !done;
+            if (!__builtin_amdgcn_ballot_w64(go)) break;
+            if (go) alpha = next; else done = true;         // a finished lane keeps its alpha (T, g belong to it)
+        }
+    };
+    // second-order polish without another evaluation: T(a*) = T(a) - g^2 / (2 g') — only where Newton converged in the interior;
+    // a minimum pinned at an end of the bracket keeps T(alpha)
+    auto polish = [&](R& alpha, R& T, R g, R gp) -> bool {
+        const bool interior = gp > R(0) && (fabs(g) <= gp * (R(16) * tol) || fabs(g * g) <= gp * (R(16) * tolT));
+        const R dal = interior ? -g * rcp_r<R>(gp) : R(0);
+        T = interior ? T + R(0.5) * g * dal : T;
+        alpha += dal;
+        return interior;
+    };
+    // The whole interval for a wave that holds suspect lanes: T and g at RTUS_LENS_SCAN + 1 even samples (any sample is an upper
+    // bound of the least time: the ends — a pinned minimum — come in here), and in every cell whose ends say "a minimum inside"
+    // (g < 0 left, g >= 0 right: 0.055 rad per cell against features of T that are ~1 rad wide) the safeguarded iteration from
+    // the secant's zero.  The least T of all of it and of the local solve wins; only suspect lanes take it.
+    auto scan = [&](R& bA, R& bT, R& bGp) {
+        constexpr int NS = 32;
+        const R dA = (a_hi - a_lo) * R(1.0 / NS);
+        R pa = a_lo, pT, pg, dummy = R(0);
+        lens_time<R, false, POLY>(k, pa, xa_cur, za_cur, xf, zf, pT, pg, dummy);
+        if (pT < bT) { bT = pT; bA = pa; bGp = R(0); }
+        for (int j = 1; j <= NS; ++j) {
+            const R ca = j == NS ? a_hi : fma((R)j, dA, a_lo);
+            R cT, cg;
+            lens_time<R, false, POLY>(k, ca, xa_cur, za_cur, xf, zf, cT, cg, dummy);
+            if (cT < bT) { bT = cT; bA = ca; bGp = R(0); }
+            const bool cell = pg < R(0) && cg >= R(0);
+            if (__builtin_amdgcn_ballot_w64(cell)) {         // wave-uniform
+                R x = cell ? pa + (ca - pa) * (pg * rcp_r<R>(pg - cg)) : R(0.5) * (pa + ca);
+                x = fmin(fmax(x, pa), ca);
+                R T, g, gp = R(0);
+                iterate(x, pa, ca, T, g, gp);
+                const bool interior = polish(x, T, g, gp);
+                if (cell && T < bT) { bT = T; bA = x; bGp = interior ? gp : R(0); }
+            }
+            pa = ca; pT = cT; pg = cg;
+        }
+    };
+    int good = 0;                                            // elements in a row, up to the latest, whose ONE evaluation was enough (wave-uniform)
+    auto generic = [&](int idx, int mode, bool try_lite) {
+        xa_cur = rec[idx].xa; za_cur = rec[idx].za;
+        R alpha;
+        if (mode == 2) {
+            const float w1 = rec[idx].w1, w3 = rec[idx].w3;
+            alpha = al1 + ((R)(w1 - 1.0f) * (al1 - al2) + (R)w3 * (al3 - al2));
+        } else if (mode == 1) {
+            alpha = al1;
+        } else {
+            // first guess: polar angle of the point where the straight chord A-F meets the lens apex height
+            const R hz = -(k.phi_3 - k.twoTc + sqrt((k.phi_3 - k.twoTc) * (k.phi_3 - k.twoTc) - k.C4A)) * k.inv2A;
+            const R t = (za_cur - hz) / (za_cur - zf);
+            alpha = atan2(xa_cur + t * (xf - xa_cur), hz);
+        }
+        alpha = fmin(fmax(alpha, a_lo), a_hi);
+        const R start = alpha;
+        R T, g, gp = R(0);
+        bool one = false;                                    // wave-uniform: the lite step was enough
+        if (try_lite && mode == 2 && rgp_bad == 0) {         // as in the fast rows
+            lens_time<R, false, POLY>(k, alpha, xa_cur, za_cur, xf, zf, T, g, gp);
+            const R step = -g * rgp;
+            const unsigned long long big = (__builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT))
+                                         | __builtin_amdgcn_ballot_w64(rgp * fma(gp_dx, fabs(xa_cur - x_full), gp_min) > R(1));
+            LDBG(2);
+            if (!big) {
+                LDBG(3);
+                T += R(0.5) * g * step;
+                alpha += step;
+                one = true;
+            }
+        }
+        if (!one) {
+            LDBG(4);
+            alpha = start;
+            iterate(alpha, a_lo, a_hi, T, g, gp);
+            const bool interior = polish(alpha, T, g, gp);
+            R gpl = interior ? gp : R(0);                    // this lane's g' at its minimum (0: none)
+            const bool sus = !(gpl >= gp_min);               // pinned, NaN, or flat enough for a second minimum to exist
+            if (__builtin_amdgcn_ballot_w64(sus)) {          // wave-uniform
+                LDBG(5);
+                R bA = alpha, bT = T, bGp = gpl;
+                scan(bA, bT, bGp);
+                if (sus) { alpha = bA; T = bT; gpl = bGp; }
+            }
+            rgp = rcp_r<R>(gpl);
+            rgp_bad = __builtin_amdgcn_ballot_w64(!(gpl > R(0)));
+            x_full = xa_cur;
+        }
+        good = one ? good + 1 : 0;
+        if (T_ONLY && nun > 0) {                             // the fast rows were left at a verified element: its measured miss corrects
+            const R ms = alpha - start;                      // the unverified starts still in the history, as a lite step's does
+            al1 += (nun == 2 ? R(0.4) : (nun == 3 ? R(0.5) : R(35.0 / 56.0))) * ms;      // (a suspect lane's minimiser may have jumped:
+            al2 += (nun == 2 ? R(0.1) : (nun == 3 ? R(0.2) : R(20.0 / 56.0))) * ms;      //  its next elements are generic steps anyway)
+            nun = 0;
+        }
+        store_at<R>(rs_t, voff, soff, T);
+        if (WA) store_at<R>(rs_a, voff, soff, alpha);
+        soff += row_bytes;
+        al3 = al2; al2 = al1; al1 = alpha;
+    };
+
     int li = 0;
     while (li < ne) {                                        // wave-uniform
         const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
-        if (mode == 2) {
-            // the run of mode-2 elements from here on, unrolled by three so that the history rotates through its
-            // registers without moves
-            const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
-            for (int t = run / 3; t > 0; --t) {
-                if (T_ONLY && lite_ok && skip_next) {        // every other triple of a good streak does not verify at all
-                    step2t(li, al1, al2, al3);
+        const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
+        bool left = false;                                   // the fast rows were left at a lite step that failed: no second try
+        if (mode == 2 && run >= 3 && rgp_bad == 0 && (!T_ONLY || good >= 2)) {
+            // the run of mode-2 elements from here on, unrolled by three so that the history rotates through its registers
+            // without moves; left at the first lite step that fails (rot = how far into its triple).  T_ONLY tables come here after
+            // two elements in a row that needed one evaluation, and start with a triple of T-only rows.
+            int rot = 0;
+            nun = 0;
+            bool skip_next = true;                           // the next triple starts unverified as well
+            int t = run / 3;
+            for (; t > 0; --t) {
+                if (T_ONLY && skip_next) {                   // every other triple does not verify at all
+                    tonly(li, al1, al2, al3);
                     skip_next = false;
                     nun += 1;
                 } else {
-                    step2(li, al1, al2, al3);                // newest .. oldest = al3, al1, al2
+                    if (!lite(li, al1, al2, al3)) { rot = 0; break; }   // newest .. oldest = al3, al1, al2
                     // n unverified starts in a row are off by C(k+2, 3) tau (k = 1..n) and the verified one after them by C(n+3, 3) tau
                     // = miss: the two still in the history (k = n, n - 1) are corrected by their share of it (n = 2, 3 or 5)
                     if (T_ONLY && nun > 0) {
@@ -400,42 +502,28 @@ __global__ __launch_bounds__(RTUS_BLOCK) void rtus_tt_lens_kernel(LensFermatArgs
                     nun = 0;
                 }
                 LDBG(0);
-                if (T_ONLY && lite_ok) {
+                if (T_ONLY) {
                     LDBG(1);
-                    step2t(li + 1, al3, al1, al2);
-                    step2t(li + 2, al2, al3, al1);
+                    tonly(li + 1, al3, al1, al2);
+                    tonly(li + 2, al2, al3, al1);
                     nun += 2;
                 } else {
-                    step2(li + 1, al3, al1, al2);            //                    al2, al3, al1
-                    step2(li + 2, al2, al3, al1);            //                    al1, al2, al3
-                    nun = 0;
+                    if (!lite(li + 1, al3, al1, al2)) { rot = 1; break; }   //                    al2, al3, al1
+                    if (!lite(li + 2, al2, al3, al1)) { rot = 2; break; }   //                    al1, al2, al3
                 }
                 li += 3;
             }
-            nun = 0;
-            for (int t = run % 3; t > 0; --t) {
-                step2(li, al1, al2, al3);
-                const R tn = al3; al3 = al2; al2 = al1; al1 = tn;
-                li += 1;
+            if (t == 0) nun = 0;
+            if (t > 0) {                                     // left early: the history back in canonical order
+                if (rot == 1) { const R n = al3; al3 = al2; al2 = al1; al1 = n; }
+                if (rot == 2) { const R n = al2, m = al3; al3 = al1; al1 = n; al2 = m; }
+                li += rot;
+                left = true;
+            } else if (li >= ne || __builtin_amdgcn_readfirstlane(rec[li].mode) != 2) {
+                continue;
             }
-            continue;
         }
-        const R xa = rec[li].xa, za = rec[li].za;
-        R alpha;
-        if (mode == 1) {
-            alpha = al1;
-        } else {
-            // first guess: polar angle of the point where the straight chord A-F meets the lens apex height
-            const R hz = -(k.phi_3 - k.twoTc + sqrt((k.phi_3 - k.twoTc) * (k.phi_3 - k.twoTc) - k.C4A)) * k.inv2A;
-            const R t = (za - hz) / (za - zf);
-            alpha = atan2(xa + t * (xf - xa), hz);
-        }
-        R T;
-        const R asol = solve(alpha, xa, za, false, T);
-        store_at<R>(rs_t, voff, soff, T);
-        if (WA) store_at<R>(rs_a, voff, soff, asol);
-        soff += row_bytes;
-        al3 = al2; al2 = al1; al1 = asol;
+        generic(li, mode, !left);
         ++li;
     }
 }
@@ -454,6 +542,8 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     k.xe = xe; k.ze = ze; k.xf = xf; k.zf = zf; k.tt = tt; k.alpha_out = alpha_out;
     k.n_e = n_e; k.n_f = n_f;
     k.poly_trig = (a_lo >= -1.0 && a_hi <= 1.0) ? 1 : 0;
+    // the lens's own time and speed scale the two constants measured on the reference lens (h0 / c2 = 5.96e-5 s: 1.5e-5 and 2e-3)
+    k.gp_min = (R)(0.25 * L.h0 / L.c2); k.gp_dx = (R)(3.0 / L.c2);
     k.eb = rtus_rows_per_block(n_rows_total, n_f, 1, (int)sizeof(R));   // of the WHOLE table: row shards reproduce its bits
     if (k.eb < 1 || (n_rows_total + k.eb - 1) / k.eb > 65535) return hipErrorInvalidValue;
     k.row0 = row0;

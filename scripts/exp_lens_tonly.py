@@ -20,4 +20,4 @@ L.rtus_dbg_read_lens(buf)
 dev_api.tt_lens_rows_dev(xe, ze, xf, zf, out, params=p, row0=0, n_rows_total=1024)
 L.rtus_dbg_read_lens(buf)
 v = list(buf)
-print("triples", v[0], "with T-only rows", v[1], "| lite attempts", v[2], "lite ok", v[3], "| full iterations", v[4], "of which because some lane has no usable g1", v[5], "| trips of the full iteration", v[6])
+print("triples", v[0], "with T-only rows", v[1], "| lite attempts", v[2], "lite ok", v[3], "| full iterations", v[4], "of which because some lane has no usable g1", v[5], "| trips of the full iteration", v[6], "| lite steps left because a lane looks flat", v[7])
