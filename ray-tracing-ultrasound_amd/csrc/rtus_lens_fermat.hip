@@ -211,6 +211,7 @@ template <typename R> struct __attribute__((aligned(16))) LensRec {
     float w1, w3;            // Lagrange weights of the newest / oldest of the three previous solutions (w2 = 1 - w1 - w3)
     int mode;                // 0: no history, 1: previous alpha, 2: extrapolate
     int run;                 // number of consecutive mode-2 elements from this one on (inside the workgroup's block)
+    float reach;             // the farthest any element of the block lies from this one (m): how far g' can drift before the block ends
 };
 
 // A workgroup = 256 targets x `eb` consecutive elements.  The minimiser alpha*(element) is smooth in the element
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
 {
     __shared__ LensRec<R> rec[128];                          // eb <= 128 (fp32 tables; 64 for fp64: rtus_rows_per_block)
     __shared__ unsigned long long m2s[2];                    // per header wave: which of its elements extrapolate (mode 2)
+    __shared__ float xext[4];                                // per header wave: least and greatest element position (block extent)
     const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         r.w3 = quad ? q3 : 0.0f;
         r.mode = lin ? 2 : (hist >= 1 ? 1 : 0);
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(r.mode == 2 && idx < ne);
-        if (lane == 0) m2s[idx >> 6] = m2;
+        float xmn = (float)xe_v, xmx = (float)xe_v;          // (idx >= ne repeats the last element: no effect on the extent)
+        for (int sh = 32; sh > 0; sh >>= 1) { xmn = fminf(xmn, __shfl_xor(xmn, sh)); xmx = fmaxf(xmx, __shfl_xor(xmx, sh)); }
+        if (lane == 0) { m2s[idx >> 6] = m2; xext[2 * (idx >> 6)] = xmn; xext[2 * (idx >> 6) + 1] = xmx; }
     }
     __syncthreads();
     if (idx < 128) {
@@ -262,10 +266,12 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         const int here = rest ? __ffsll((long long)rest) - 1 : 64 - lane;
         const int more = (here == 64 - lane && idx < 64) ? (~next ? __ffsll((long long)~next) - 1 : 64) : 0;   // (the shift fills `rest` with ones from bit 64 - lane on)
         r.run = (r.mode == 2 && idx < ne) ? here + more : 0;
+        const float xlo = fminf(xext[0], xext[2]), xhi = fmaxf(xext[1], xext[3]);
+        r.reach = fmaxf(xhi - (float)r.xa, (float)r.xa - xlo) * (1.0f + 1e-6f);
         rec[idx] = r;
     }
     __syncthreads();
-    const LensConst<R> k = lens_const<R>(a);
+    LensConst<R> k = lens_const<R>(a);                       // (re-made after a scan, which works from the kernel arguments: see there)
     R a_lo = a.a_lo, a_hi = a.a_hi;
     if (sizeof(R) == 4) asm("" : "+v"(a_lo), "+v"(a_hi));
     // |d alpha| below which a lane stops iterating (rad).  The step it would have taken is still applied — to alpha
@@ -283,7 +289,6 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
     R al1 = R(0), al2 = R(0), al3 = R(0);                   // solutions of the three previous elements (al1 the newest)
     R rgp = R(0);                                           // 1 / g' of this lane's latest full evaluation (usable if that solve
                                                             // ended at an interior minimum: rgp_bad below)
-    R x_full = R(0);                                        // position of the element that evaluation belonged to (wave-uniform)
     const unsigned row_bytes = (unsigned)a.n_f * (unsigned)sizeof(R);
     const unsigned blk_bytes = (unsigned)ne * row_bytes;     // < 2^32: the launcher sizes eb for it
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(a.tt + (size_t)e0 * a.n_f, 0, blk_bytes, 0x00020000);
@@ -300,12 +305,14 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
     // follows one of them; the table entry is the lesser (Fermat).  Measured on the CPU over the water below the reference lens
     // (elements within +-20 mm, 4,001 samples of alpha per pair): wherever a pair has more than one local
     // minimum, g' at every INTERIOR one is <= 3.7e-6 s/rad^2, against >= 3e-5 on tables away from the focus (BASELINE configs[3]:
-    // 2.9e-5 ... 2.3e-4).  So a lane is SUSPECT when its minimum is pinned at an end of the interval or its latest g' is below
-    // gp_min (= 1.5e-5 for the reference lens: four times the bound) + gp_dx |x_e - x_full| (g' at the followed minimum moves by
-    // <= 1.2e-3 s/rad^2 per metre of element position; the lite steps below do not refresh it); a suspect wave leaves the fast rows
-    // for the generic step, which looks at the whole interval (`scan`).  Not suspect => one minimum => the continuation is right.
-    R gp_min = a.gp_min, gp_dx = a.gp_dx;
-    if (sizeof(R) == 4) asm("" : "+v"(gp_min), "+v"(gp_dx));
+    // 2.9e-5 ... 2.3e-4).  So a lane is SUSPECT when its minimum is pinned at an end of the interval or its g' there is below
+    // gp_min (= 1.5e-5 for the reference lens: four times the bound): the generic step then looks at the whole interval (`scan`).
+    // The fast rows below do not evaluate g'; it moves by <= 1.2e-3 s/rad^2 per metre of element position along the followed
+    // minimum, so they run only while the latest full evaluation says g' >= gp_min + gp_dx * (the farthest any element of the block
+    // is from that one) in every lane: no element of the block can be suspect then.  Not suspect => one minimum => the
+    // continuation is right.
+    const R gp_min = a.gp_min, gp_dx = a.gp_dx;              // (only the generic step reads them: scalar operands will do)
+    unsigned long long flat_ahead = ~0ull;                   // lanes whose g' could fall below gp_min before the block ends (wave-uniform mask)
 
     // ---- the fast rows: elements of a run (mode 2), every lane with a usable, unsuspicious g' ----------------------------------
     // ONE evaluation of T and g at the start extrapolated from the three previous solutions (n1 the newest; differences first:
@@ -321,11 +328,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         R T, g, gp = R(0);
         lens_time<R, false, POLY>(k, alpha, xa, za, xf, zf, T, g, gp);
         const R step = -g * rgp;
-        const unsigned long long flat = __builtin_amdgcn_ballot_w64(rgp * fma(gp_dx, fabs(xa - x_full), gp_min) > R(1));
-        const unsigned long long big = (__builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT)) | flat;
+        const unsigned long long big = __builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT);
         LDBG(2);
-        if (flat) LDBG(7);
-        if (big) return false;
+        if (big) { miss = step; return false; }              // (the generic step starts its iteration one Newton step on: `miss`)
         LDBG(3);
         miss = step;
         store_at<R>(rs_t, voff, soff, T + R(0.5) * g * step);    // T(a*) = T(a) - g^2 / (2 g')
@@ -383,35 +388,62 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         alpha += dal;
         return interior;
     };
-    // The whole interval for a wave that holds suspect lanes: T and g at RTUS_LENS_SCAN + 1 even samples (any sample is an upper
-    // bound of the least time: the ends — a pinned minimum — come in here), and in every cell whose ends say "a minimum inside"
-    // (g < 0 left, g >= 0 right: 0.055 rad per cell against features of T that are ~1 rad wide) the safeguarded iteration from
-    // the secant's zero.  The least T of all of it and of the local solve wins; only suspect lanes take it.
-    auto scan = [&](R& bA, R& bT, R& bGp) {
-        constexpr int NS = 32;
-        const R dA = (a_hi - a_lo) * R(1.0 / NS);
-        R pa = a_lo, pT, pg, dummy = R(0);
-        lens_time<R, false, POLY>(k, pa, xa_cur, za_cur, xf, zf, pT, pg, dummy);
-        if (pT < bT) { bT = pT; bA = pa; bGp = R(0); }
+    // The whole interval for a wave that holds suspect lanes: T and g at NS + 1 even samples (any sample is an upper bound of the
+    // least time: the ends — a pinned minimum — come in here), and in every cell whose ends say "a minimum inside" (g < 0 left,
+    // g >= 0 right: 0.055 rad per cell against features of T that are ~1 rad wide) the zero of g by the Illinois variant of regula
+    // falsi, a fixed number of evaluations of T and g (no g', no second derivatives: few registers — this is the rare path, and the
+    // table's common rows must not pay for it in occupancy).  T at the zero needs no polish (stationary).  The least T of all of
+    // it and of the local solve wins; only suspect lanes take it.  Returns with `moved` = the scan's own minimum was taken.
+    auto scan = [&](R& bA, R& bT, bool& moved) {
+        constexpr int NS = 32, NI = sizeof(R) == 4 ? 12 : 28;
+        // the lens constants and the interval straight from the kernel arguments (scalar operands: half rate in fp32, which does not
+        // matter here): the per-lane copies the fast rows use are dead across the scan and made again after it — eight registers
+        LensConst<R> ks;
+        ks.c1inv = a.c1inv; ks.c2inv = a.c2inv; ks.phi_3 = a.phi_3; ks.twoTc = a.twoTc; ks.C4A = a.C4A; ks.inv2A = a.inv2A; ks.poly_trig = a.poly_trig;
+        const R s_lo = a.a_lo, s_hi = a.a_hi;
+        const R dA = (s_hi - s_lo) * R(1.0 / NS);
+        R pa = s_lo, pg, dummy = R(0);
+        asm("" : "+v"(pa) : "v"(xa_cur));                    // (or the first sample's target-side half is hoisted to the top of the kernel and spilled)
+        {
+            R pT;
+            lens_time<R, false, POLY>(ks, pa, xa_cur, za_cur, xf, zf, pT, pg, dummy);
+            if (pT < bT) { bT = pT; bA = pa; moved = true; }
+        }
         for (int j = 1; j <= NS; ++j) {
-            const R ca = j == NS ? a_hi : fma((R)j, dA, a_lo);
+            const R ca = j == NS ? s_hi : fma((R)j, dA, s_lo);
             R cT, cg;
-            lens_time<R, false, POLY>(k, ca, xa_cur, za_cur, xf, zf, cT, cg, dummy);
-            if (cT < bT) { bT = cT; bA = ca; bGp = R(0); }
+            lens_time<R, false, POLY>(ks, ca, xa_cur, za_cur, xf, zf, cT, cg, dummy);
+            if (cT < bT) { bT = cT; bA = ca; moved = true; }
             const bool cell = pg < R(0) && cg >= R(0);
             if (__builtin_amdgcn_ballot_w64(cell)) {         // wave-uniform
-                R x = cell ? pa + (ca - pa) * (pg * rcp_r<R>(pg - cg)) : R(0.5) * (pa + ca);
-                x = fmin(fmax(x, pa), ca);
-                R T, g, gp = R(0);
-                iterate(x, pa, ca, T, g, gp);
-                const bool interior = polish(x, T, g, gp);
-                if (cell && T < bT) { bT = T; bA = x; bGp = interior ? gp : R(0); }
+                // (lo, glo < 0), (hi, ghi >= 0); a lane without a minimum in this cell iterates on a made-up bracket and keeps nothing
+                R lo = pa, glo = cell ? pg : R(-1), hi = ca, ghi = cell ? cg : R(1);
+                int side = 0;                                // which end the latest iterate replaced (Illinois: the other one's g is halved
+                for (int it = 0; it < NI; ++it) {            //  when the same end is replaced twice in a row)
+                    R x = lo - glo * (hi - lo) * rcp_r<R>(ghi - glo);
+                    x = (x > lo && x < hi) ? x : R(0.5) * (lo + hi);
+                    R T, g;
+                    lens_time<R, false, POLY>(ks, x, xa_cur, za_cur, xf, zf, T, g, dummy);
+                    if (T < bT && cell) { bT = T; bA = x; moved = true; }
+                    if (g < R(0)) { lo = x; glo = g; ghi = side < 0 ? R(0.5) * ghi : ghi; side = -1; }
+                    else { hi = x; ghi = g; glo = side > 0 ? R(0.5) * glo : glo; side = 1; }
+                }
             }
-            pa = ca; pT = cT; pg = cg;
+            pa = ca; pg = cg;
+        }
+    };
+    // the fast rows were left at a verified element: its measured miss corrects the unverified starts still in the history, as a
+    // lite step's does (before any scan: a suspect lane's minimiser may jump, the local solve's miss is what the history needs)
+    auto hist_fix = [&](R ms) {
+        if (T_ONLY && nun > 0) {
+            al1 += (nun == 2 ? R(0.4) : (nun == 3 ? R(0.5) : R(35.0 / 56.0))) * ms;
+            al2 += (nun == 2 ? R(0.1) : (nun == 3 ? R(0.2) : R(20.0 / 56.0))) * ms;
+            nun = 0;
         }
     };
     int good = 0;                                            // elements in a row, up to the latest, whose ONE evaluation was enough (wave-uniform)
     auto generic = [&](int idx, int mode, bool try_lite) {
+        bool took_lite = !try_lite;                          // a lite step at this element's start has been evaluated (here or in the fast rows)
         xa_cur = rec[idx].xa; za_cur = rec[idx].za;
         R alpha;
         if (mode == 2) {
@@ -429,43 +461,47 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         const R start = alpha;
         R T, g, gp = R(0);
         bool one = false;                                    // wave-uniform: the lite step was enough
-        if (try_lite && mode == 2 && rgp_bad == 0) {         // as in the fast rows
+        // a run's first elements extrapolate from fewer than three solutions (w3 = 0): their lite step nearly always fails
+        if (try_lite && mode == 2 && (rgp_bad | flat_ahead) == 0 && __builtin_amdgcn_readfirstlane(__float_as_int(rec[idx].w3)) != 0) {   // as in the fast rows
             lens_time<R, false, POLY>(k, alpha, xa_cur, za_cur, xf, zf, T, g, gp);
             const R step = -g * rgp;
-            const unsigned long long big = (__builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT))
-                                         | __builtin_amdgcn_ballot_w64(rgp * fma(gp_dx, fabs(xa_cur - x_full), gp_min) > R(1));
+            const unsigned long long big = __builtin_amdgcn_ballot_w64(fabs(step) > tol) & __builtin_amdgcn_ballot_w64(fabs(g * step) > tolT);
             LDBG(2);
+            miss = step;
+            took_lite = true;
             if (!big) {
                 LDBG(3);
                 T += R(0.5) * g * step;
                 alpha += step;
+                hist_fix(step);
                 one = true;
             }
         }
         if (!one) {
             LDBG(4);
-            alpha = start;
+            // the fast rows' failed lite step (or the one just above) has evaluated `start` already: the iteration begins one
+            // Newton step on (with the previous element's g': iterate() takes it from there, inside the interval)
+            alpha = fmin(fmax(start + (took_lite ? miss : R(0)), a_lo), a_hi);
             iterate(alpha, a_lo, a_hi, T, g, gp);
             const bool interior = polish(alpha, T, g, gp);
+            hist_fix(alpha - start);
             R gpl = interior ? gp : R(0);                    // this lane's g' at its minimum (0: none)
             const bool sus = !(gpl >= gp_min);               // pinned, NaN, or flat enough for a second minimum to exist
             if (__builtin_amdgcn_ballot_w64(sus)) {          // wave-uniform
                 LDBG(5);
-                R bA = alpha, bT = T, bGp = gpl;
-                scan(bA, bT, bGp);
-                if (sus) { alpha = bA; T = bT; gpl = bGp; }
+                R bA = alpha, bT = T;
+                bool moved = false;
+                scan(bA, bT, moved);
+                if (sus) { alpha = bA; T = bT; gpl = moved ? R(0) : gpl; }   // (no g' at a minimum the scan found: the next element is a generic step)
+                k = lens_const<R>(a);
+                a_lo = a.a_lo; a_hi = a.a_hi;
+                if (sizeof(R) == 4) asm("" : "+v"(a_lo), "+v"(a_hi));
             }
             rgp = rcp_r<R>(gpl);
             rgp_bad = __builtin_amdgcn_ballot_w64(!(gpl > R(0)));
-            x_full = xa_cur;
+            flat_ahead = __builtin_amdgcn_ballot_w64(!(gpl >= fma(gp_dx, (R)rec[idx].reach, gp_min)));
         }
         good = one ? good + 1 : 0;
-        if (T_ONLY && nun > 0) {                             // the fast rows were left at a verified element: its measured miss corrects
-            const R ms = alpha - start;                      // the unverified starts still in the history, as a lite step's does
-            al1 += (nun == 2 ? R(0.4) : (nun == 3 ? R(0.5) : R(35.0 / 56.0))) * ms;      // (a suspect lane's minimiser may have jumped:
-            al2 += (nun == 2 ? R(0.1) : (nun == 3 ? R(0.2) : R(20.0 / 56.0))) * ms;      //  its next elements are generic steps anyway)
-            nun = 0;
-        }
         store_at<R>(rs_t, voff, soff, T);
         if (WA) store_at<R>(rs_a, voff, soff, alpha);
         soff += row_bytes;
@@ -477,7 +513,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         const int mode = __builtin_amdgcn_readfirstlane(rec[li].mode);
         const int run = __builtin_amdgcn_readfirstlane(rec[li].run);
         bool left = false;                                   // the fast rows were left at a lite step that failed: no second try
-        if (mode == 2 && run >= 3 && rgp_bad == 0 && (!T_ONLY || good >= 2)) {
+        if (mode == 2 && run >= 3 && (rgp_bad | flat_ahead) == 0 && (!T_ONLY || good >= 2)) {
             // the run of mode-2 elements from here on, unrolled by three so that the history rotates through its registers
             // without moves; left at the first lite step that fails (rot = how far into its triple).  T_ONLY tables come here after
             // two elements in a row that needed one evaluation, and start with a triple of T-only rows.

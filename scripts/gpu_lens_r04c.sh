@@ -12,4 +12,5 @@ for i in 1 2; do
   timeout -k 10 120 python3 scripts/ab_lens_f64.py 2>&1 | tail -2
 done | tee $OUT/ab64.txt
 timeout -k 10 900 python3 -m pytest tests/test_gpu_lens_rows.py -q -m gpu -s > $OUT/rows.txt 2>&1; echo "rows rc $?" >> $OUT/rows.txt
-grep -E "rows/workgroup|passed|failed|rc |Error|assert" $OUT/rows.txt | cut -c1-100,220-400
+grep -E "rows/workgroup|passed|failed|rc |Error|assert" $OUT/rows.txt | cut -c1-60,200-400
+bash scripts/pmc_lens_ab.sh 2>&1 | tail -4
