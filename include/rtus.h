@@ -253,7 +253,7 @@ int rtus_sweep(const rtus_lens *lens, const double *geoms, int n_geom,
  * single round of 4 waves per SIMD) no longer pays a launch ramp and drain of its own.
  * ---------------------------------------------------------------------------------------- */
 #define RTUS_MAX_LAYERS 8
-/* Accuracy tier of the planar solver (flags of rtus_tt_layers_rows_dev / rtus_tt_layers_multi*).  0: the travel time from an fp64
+/* Accuracy tier of the planar solver (flags of the *_ex entries, rtus_tt_layers_rows_dev, rtus_tt_layers_sorted_dev).  0: the travel time from an fp64
  * evaluation at the Newton iterate + its second-order Fermat expansion in an fp64 residual: <= 1e-13 relative (measured 3e-18 s
  * on BASELINE config 3).  RTUS_TT_TAUP_TAIL: from the tau-p form T = p X + sum (h_i/c_i) cos(theta_i), stationary in p, with the
  * second-order term from the fp32 residual: four fp64 instructions fewer per solve, <= 6e-11 relative (~2e-15 s) at worst,
@@ -274,6 +274,22 @@ int rtus_tt_layers(const double *z_if, const double *c, int n_if,
                    const double *xe, const double *ze, int n_e,
                    const double *xf, const double *zf, int n_f,
                    double *tt, uint8_t *iters, int device);
+
+/* The same entries with the accuracy tier as an argument (flags: 0 or RTUS_TT_TAUP_TAIL; the un-suffixed entries above are
+ * flags = 0).  iters is a diagnostic of the default tier's kernel: RTUS_ERR_INVALID_ARG with RTUS_TT_TAUP_TAIL.  bench.py's
+ * headline times RTUS_TT_TAUP_TAIL; every caller — device pointers, host buffers, batches, several GPUs (below) — can ask for it. */
+int rtus_tt_layers_ex_dev(const double *z_if, const double *c, int n_if,
+                          const double *d_xe, const double *d_ze, int n_e,
+                          const double *d_xf, const double *d_zf, int n_f,
+                          double *d_tt, uint8_t *d_iters, unsigned flags, void *stream);
+int rtus_tt_layers_batch_ex_dev(const double *z_if, const double *c, int n_if,
+                                const double *d_xe, const double *d_ze, int n_e, long long e_stride,
+                                const double *d_xf, const double *d_zf, int n_f, long long f_stride,
+                                double *d_tt, long long t_stride, int n_batch, unsigned flags, void *stream);
+int rtus_tt_layers_ex(const double *z_if, const double *c, int n_if,
+                      const double *xe, const double *ze, int n_e,
+                      const double *xf, const double *zf, int n_f,
+                      double *tt, uint8_t *iters, unsigned flags, int device);
 
 /* The aperture in ANY order.  The kernel starts each solve from the four previous elements of its workgroup's block, which pays
  * (1 evaluation instead of ~4.5) when consecutive elements are neighbours in space at one depth.  rtus_tt_layers_dev takes the
@@ -353,12 +369,33 @@ int rtus_tt_lens_f32_rows_dev(const rtus_lens *lens, double alpha_lo, double alp
                               const float *d_xe, const float *d_ze, int n_rows, long long row0, long long n_rows_total,
                               const float *d_xf, const float *d_zf, int n_f, float *d_tt, float *d_alpha_out, void *stream);
 
+/* Diagnostic: the rows of rtus_tt_lens[_f32]_rows_dev (no alpha output) plus HOW they were solved, added to d_stats (device memory,
+ * 5 x uint64, zeroed by the caller), counted in wave-elements (64 targets of one row): [0] T alone at the extrapolated start,
+ * [1] one evaluation of T and dT/dalpha, [2] the safeguarded iteration, [3] of those: with a look at the whole search interval
+ * (a target pinned at an end of it, or T nearly flat in alpha — around the lens focus two minima compete), [4] evaluations in [2]. */
+int rtus_tt_lens_stats_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                           const double *d_xe, const double *d_ze, int n_rows, long long row0, long long n_rows_total,
+                           const double *d_xf, const double *d_zf, int n_f, double *d_tt, unsigned long long *d_stats, void *stream);
+int rtus_tt_lens_f32_stats_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
+                               const float *d_xe, const float *d_ze, int n_rows, long long row0, long long n_rows_total,
+                               const float *d_xf, const float *d_zf, int n_f, float *d_tt, unsigned long long *d_stats, void *stream);
+
 int rtus_tt_layers_multi(const double *z_if, const double *c, int n_if,
                          const double *xe, const double *ze, int n_e, const double *xf, const double *zf, int n_f,
                          double *tt, const int *devices, int n_dev);
 int rtus_tt_lens_f32_multi(const rtus_lens *lens, double alpha_lo, double alpha_hi,
                            const float *xe, const float *ze, int n_e, const float *xf, const float *zf, int n_f,
                            float *tt, const int *devices, int n_dev);
+
+/* ... with the accuracy tier (flags: 0 or RTUS_TT_TAUP_TAIL).  rtus_tt_layers_multi[_ex] sorts the aperture by (depth, position) on
+ * the host first, as rtus_tt_layers does: the table is the one-device table bit for bit whatever order the elements come in. */
+int rtus_tt_layers_multi_ex(const double *z_if, const double *c, int n_if,
+                            const double *xe, const double *ze, int n_e, const double *xf, const double *zf, int n_f,
+                            double *tt, const int *devices, int n_dev, unsigned flags);
+int rtus_tt_layers_multi_ex_dev(const double *z_if, const double *c, int n_if,
+                                const double *const *d_xe, const double *const *d_ze, int n_e,
+                                const double *const *d_xf, const double *const *d_zf, int n_f, double *const *d_tt,
+                                const int *devices, int n_dev, void *const *streams, int gather, unsigned flags);
 
 int rtus_tt_layers_multi_dev(const double *z_if, const double *c, int n_if,
                              const double *const *d_xe, const double *const *d_ze, int n_e,

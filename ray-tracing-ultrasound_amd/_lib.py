@@ -136,6 +136,24 @@ def lib():
     pp = C.POINTER(C.c_void_p)
     L.rtus_tt_layers_multi_dev.argtypes = [dp, dp, ip, pp, pp, ip, pp, pp, ip, pp, C.POINTER(C.c_int), ip, pp, ip]
     L.rtus_tt_lens_f32_multi_dev.argtypes = [LP, C.c_double, C.c_double, pp, pp, ip, pp, pp, ip, pp, C.POINTER(C.c_int), ip, pp, ip]
+    try:
+        L.rtus_tt_lens_stats_dev.argtypes = [LP, C.c_double, C.c_double, dp, dp, ip, ll, ll, dp, dp, ip, dp, vp, vp]
+        L.rtus_tt_lens_f32_stats_dev.argtypes = L.rtus_tt_lens_stats_dev.argtypes
+        L.rtus_tt_lens_stats_dev.restype = ip
+        L.rtus_tt_lens_f32_stats_dev.restype = ip
+        # the planar entries with the accuracy tier as an argument (flags: RTUS_TT_TAUP_TAIL or 0)
+        up = C.c_uint
+        L.rtus_tt_layers_ex_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, up, vp]
+        L.rtus_tt_layers_ex.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, up, ip]
+        L.rtus_tt_layers_batch_ex_dev.argtypes = [dp, dp, ip, dp, dp, ip, ll, dp, dp, ip, ll, dp, ll, ip, up, vp]
+        L.rtus_tt_layers_multi_ex.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, C.POINTER(C.c_int), ip, up]
+        L.rtus_tt_layers_multi_ex_dev.argtypes = [dp, dp, ip, pp, pp, ip, pp, pp, ip, pp, C.POINTER(C.c_int), ip, pp, ip, up]
+        for name in ("rtus_tt_layers_ex_dev", "rtus_tt_layers_ex", "rtus_tt_layers_batch_ex_dev", "rtus_tt_layers_multi_ex",
+                     "rtus_tt_layers_multi_ex_dev", "rtus_tt_lens_stats_dev", "rtus_tt_lens_f32_stats_dev"):
+            getattr(L, name).restype = ip
+    except AttributeError:                # a build from before round 4, loaded through RTUS_LIB for an A/B run: it lacks these entries
+        if not os.environ.get("RTUS_LIB"):
+            raise
     for name in ("rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev", "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi",
                  "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev", "rtus_tt_lens_f32_multi_dev"):
         getattr(L, name).restype = ip
@@ -159,4 +177,6 @@ EXPORTS = ("rtus_strerror", "rtus_version", "rtus_last_hip_error", "rtus_device_
            "rtus_focal_delays_dev", "rtus_focal_delays", "rtus_tfm_dev", "rtus_tfm",
            "rtus_tt_layers_sort_workspace_bytes", "rtus_tt_layers_sorted_dev", "rtus_table_rows_per_block", "rtus_shard_rows", "rtus_tt_layers_rows_dev", "rtus_tt_lens_rows_dev",
            "rtus_tt_lens_f32_rows_dev", "rtus_tt_layers_multi", "rtus_tt_lens_f32_multi", "rtus_tt_layers_multi_dev",
-           "rtus_tt_lens_f32_multi_dev", "rtus_sweep_workspace_bytes", "rtus_sweep_dev", "rtus_sweep")
+           "rtus_tt_lens_f32_multi_dev", "rtus_sweep_workspace_bytes", "rtus_sweep_dev", "rtus_sweep",
+           "rtus_tt_layers_ex_dev", "rtus_tt_layers_ex", "rtus_tt_layers_batch_ex_dev", "rtus_tt_layers_multi_ex",
+           "rtus_tt_layers_multi_ex_dev", "rtus_tt_lens_stats_dev", "rtus_tt_lens_f32_stats_dev")

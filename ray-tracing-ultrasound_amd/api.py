@@ -261,12 +261,19 @@ def _device_list(devices):
     return d
 
 
-def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None, device=0, devices=None):
+TAUP_TAIL = 0x1             # RTUS_TT_TAUP_TAIL (include/rtus.h)
+
+
+def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None, device=0, devices=None, taup=False):
     """Element x focal-point Fermat travel times through horizontal layers -> tt[n_e, n_f].
 
     ``out``: optional float64 [n_e, n_f] result buffer, returned as ``tt``.
     ``devices``: a list of GPU indices — the table's rows are solved in contiguous blocks on all of them at once and each
-    GPU copies its block straight into ``tt`` (rtus_tt_layers_multi); the result is bit for bit the one-GPU table.
+    GPU copies its block straight into ``tt`` (rtus_tt_layers_multi_ex); the result is bit for bit the one-GPU table.
+    ``taup``: the faster accuracy tier (RTUS_TT_TAUP_TAIL: the tau-p form of the travel time, <= 6e-11 relative at worst,
+    measured 3e-17 s on BASELINE configs[2]; the default tier: <= 1e-13 relative) — the tier bench.py's headline times.
+    The aperture may come in any order: the rows are solved in (depth, position) order and stored where they belong, so an
+    element's bits do not depend on it (``return_iters`` takes the elements as given: it is a diagnostic of that).
 
     NOT in the reference (no planar interfaces there): parity unpinned, see DESIGN.md.
     """
@@ -277,19 +284,22 @@ def travel_time_layers(z_if, c, xe, ze, xf, zf, *, return_iters=False, out=None,
     xe, ze, xf, zf = _f64(xe, "xe"), _f64(ze, "ze"), _f64(xf, "xf"), _f64(zf, "zf")
     if xe.shape != ze.shape or xf.shape != zf.shape:
         raise ValueError("xe/ze and xf/zf must pair up")
+    if taup and return_iters:
+        raise ValueError("return_iters is a diagnostic of the default tier")
+    flags = TAUP_TAIL if taup else 0
     tt = _out(out, (xe.size, xf.size), np.float64)
     if devices is not None:
         if return_iters:
             raise ValueError("return_iters is a one-device diagnostic")
         dv = _device_list(devices)
-        st = _lib.lib().rtus_tt_layers_multi(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze), xe.size,
-                                             _ptr(xf), _ptr(zf), xf.size, _ptr(tt), dv.ctypes.data_as(C.POINTER(C.c_int)), dv.size)
-        _lib.check(st, "rtus_tt_layers_multi")
+        st = _lib.lib().rtus_tt_layers_multi_ex(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze), xe.size,
+                                                _ptr(xf), _ptr(zf), xf.size, _ptr(tt), dv.ctypes.data_as(C.POINTER(C.c_int)), dv.size, flags)
+        _lib.check(st, "rtus_tt_layers_multi_ex")
         return tt
     iters = np.empty((xe.size, xf.size), dtype=np.uint8) if return_iters else None
-    st = _lib.lib().rtus_tt_layers(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze),
-                                   xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), int(device))
-    _lib.check(st, "rtus_tt_layers")
+    st = _lib.lib().rtus_tt_layers_ex(_ptr(z_if) if z_if.size else None, _ptr(c), z_if.size, _ptr(xe), _ptr(ze),
+                                      xe.size, _ptr(xf), _ptr(zf), xf.size, _ptr(tt), _ptr(iters), flags, int(device))
+    _lib.check(st, "rtus_tt_layers_ex")
     return (tt, iters) if return_iters else tt
 
 
@@ -330,7 +340,7 @@ def travel_time_lens(xe, ze, xf, zf, *, params: Params = None, alpha_lo=None, al
     return (tt, al) if return_alpha else tt
 
 
-def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0):
+def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0, devices=None, taup=False):
     """Full-matrix-capture tx/rx travel-time table for a planar specular reflector at depth z_reflector
     under horizontal layers (BASELINE config 5).  The down-and-up path through the layers is unfolded
     about the reflector plane into a one-way path through the mirrored stack, so the table is one
@@ -345,7 +355,7 @@ def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0)
     c_m = np.concatenate([cc, cc[::-1][1:]])                            # ... and speeds (reflector layer merged)
     x_tx, x_rx = _f64(x_tx, "x_tx"), _f64(x_rx, "x_rx")
     return travel_time_layers(z_m, c_m, x_tx, np.full(x_tx.size, float(z_array)), x_rx,
-                              np.full(x_rx.size, 2.0 * z_reflector - float(z_array)), device=device)
+                              np.full(x_rx.size, 2.0 * z_reflector - float(z_array)), device=device, devices=devices, taup=taup)
 
 
 def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params: Params = None, fast=False,

@@ -34,10 +34,10 @@ hipError_t rtus_launch_match(const double* land_x, const double* tof, int n_batc
                              uint8_t* hit, double* tof_hit, uint8_t* ray_hit, hipStream_t s);
 hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
-                                 double* tt, uint8_t* iters, hipStream_t s);
+                                 double* tt, uint8_t* iters, unsigned flags, hipStream_t s);
 hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int n_if, const double* xe, const double* ze,
                                        int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
-                                       long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s);
+                                       long long f_stride, double* tt, long long t_stride, int n_batch, unsigned flags, hipStream_t s);
 hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                       int row0, long long n_rows_total, const double* xf, const double* zf, int n_f, double* tt,
                                       unsigned flags, hipStream_t s);
@@ -49,10 +49,10 @@ hipError_t rtus_launch_tt_layers_sorted(const double* z_if, const double* c, int
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
-                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s);
+                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s, unsigned long long* stats = nullptr);
 hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi, const float* xe, const float* ze,
                                    int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
-                                   int row0, long long n_rows_total, hipStream_t s);
+                                   int row0, long long n_rows_total, hipStream_t s, unsigned long long* stats = nullptr);
 
 hipError_t rtus_launch_focal_delays(const double* tt, int n_e, int n_f, double* delays, hipStream_t s);
 hipError_t rtus_launch_tfm(const float* fmc, int n_tx, int n_rx, int n_t, double fs, double t0, const double* tt_tx,
@@ -253,7 +253,7 @@ static int lens_host(const rtus_lens* lens, double a_lo, double a_hi, const R* x
     R* dtt = S.take<R>(tot);
     R* dal = alpha_out ? S.take<R>(tot) : nullptr;
     HIP_TRY(S.flush());
-    LAUNCH_TRY(launch(*lens, a_lo, a_hi, dxe, dze, n_e, dxf, dzf, n_f, dtt, dal, 0, n_e, S.a->stream));
+    LAUNCH_TRY(launch(*lens, a_lo, a_hi, dxe, dze, n_e, dxf, dzf, n_f, dtt, dal, 0, n_e, S.a->stream, nullptr));
     S.download(tt, dtt, tot);
     S.download(alpha_out, dal, tot);
     HIP_TRY(S.finish());
@@ -644,14 +644,43 @@ static int check_layers(const double* z_if, const double* c, int n_if, const voi
     return RTUS_OK;
 }
 
+// flags of the planar entries: the accuracy tier; the iteration counts are a diagnostic of the accurate tier's kernel
+static int check_tier(unsigned flags, const void* iters)
+{
+    if (flags & ~RTUS_TT_TAUP_TAIL) return RTUS_ERR_INVALID_ARG;
+    if ((flags & RTUS_TT_TAUP_TAIL) && iters) return RTUS_ERR_INVALID_ARG;
+    return RTUS_OK;
+}
+
+int rtus_tt_layers_ex_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze,
+                          int n_e, const double* d_xf, const double* d_zf, int n_f, double* d_tt, uint8_t* d_iters,
+                          unsigned flags, void* stream)
+{
+    int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_tier(flags, d_iters))) return st;
+    LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters, flags,
+                                  (hipStream_t)stream));
+    return RTUS_OK;
+}
+
 int rtus_tt_layers_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze,
                        int n_e, const double* d_xf, const double* d_zf, int n_f, double* d_tt, uint8_t* d_iters,
                        void* stream)
 {
+    return rtus_tt_layers_ex_dev(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters, 0u, stream);
+}
+
+int rtus_tt_layers_batch_ex_dev(const double* z_if, const double* c, int n_if, const double* d_xe, const double* d_ze,
+                                int n_e, long long e_stride, const double* d_xf, const double* d_zf, int n_f,
+                                long long f_stride, double* d_tt, long long t_stride, int n_batch, unsigned flags, void* stream)
+{
     int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
-    if (st) return st;
-    LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, d_iters,
-                                  (hipStream_t)stream));
+    if (st || (st = check_tier(flags, nullptr))) return st;
+    if (n_batch <= 0 || e_stride < 0 || f_stride < 0) return RTUS_ERR_INVALID_ARG;
+    if (n_batch > 1 && t_stride < (long long)n_e * n_f) return RTUS_ERR_INVALID_ARG;   // outputs of two problems would overlap
+    if (n_batch > 65535) return RTUS_ERR_UNSUPPORTED;                                   // grid.z
+    LAUNCH_TRY(rtus_launch_tt_layers_batch(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt,
+                                        t_stride, n_batch, flags, (hipStream_t)stream));
     return RTUS_OK;
 }
 
@@ -659,14 +688,8 @@ int rtus_tt_layers_batch_dev(const double* z_if, const double* c, int n_if, cons
                              int n_e, long long e_stride, const double* d_xf, const double* d_zf, int n_f,
                              long long f_stride, double* d_tt, long long t_stride, int n_batch, void* stream)
 {
-    int st = check_layers(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt);
-    if (st) return st;
-    if (n_batch <= 0 || e_stride < 0 || f_stride < 0) return RTUS_ERR_INVALID_ARG;
-    if (n_batch > 1 && t_stride < (long long)n_e * n_f) return RTUS_ERR_INVALID_ARG;   // outputs of two problems would overlap
-    if (n_batch > 65535) return RTUS_ERR_UNSUPPORTED;                                   // grid.z
-    LAUNCH_TRY(rtus_launch_tt_layers_batch(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt,
-                                        t_stride, n_batch, (hipStream_t)stream));
-    return RTUS_OK;
+    return rtus_tt_layers_batch_ex_dev(z_if, c, n_if, d_xe, d_ze, n_e, e_stride, d_xf, d_zf, n_f, f_stride, d_tt, t_stride, n_batch, 0u,
+                                       stream);
 }
 
 size_t rtus_tt_layers_sort_workspace_bytes(int n_e) { return n_e > 0 ? rtus_layers_sort_ws_bytes(n_e) : 0; }
@@ -686,25 +709,41 @@ int rtus_tt_layers_sorted_dev(const double* z_if, const double* c, int n_if, con
     return RTUS_OK;
 }
 
-int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
-                   const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int device)
+// The aperture in (depth, position) order — the order the predictor of the kernel wants; the coordinates are host memory in the
+// host-buffer twins, so the sort is the host's: an aperture that arrives in that order (the usual case) goes through unchanged
+// (`order` stays empty).  Compared on the IEEE bits made monotone — the key the device-side rank kernel uses — so the order is a
+// strict weak order whatever the values (a NaN coordinate sorts last and fails its row only).
+static unsigned long long host_order_key(double v)
+{
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static void aperture_order(const double* xe, const double* ze, int n_e, std::vector<int>& order, std::vector<double>& sx, std::vector<double>& sz)
+{
+    auto before = [&](int a, int b) {
+        const unsigned long long za = host_order_key(ze[a]), zb = host_order_key(ze[b]);
+        return za < zb || (za == zb && host_order_key(xe[a]) < host_order_key(xe[b]));
+    };
+    bool sorted = true;
+    for (int i = 1; i < n_e && sorted; ++i) sorted = !before(i, i - 1);
+    if (sorted) return;
+    order.resize(n_e);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), before);
+    sx.resize(n_e); sz.resize(n_e);
+    for (int i = 0; i < n_e; ++i) { sx[i] = xe[order[i]]; sz[i] = ze[order[i]]; }
+}
+
+int rtus_tt_layers_ex(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                      const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, unsigned flags, int device)
 {
     int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
-    if (st) return st;
+    if (st || (st = check_tier(flags, iters))) return st;
     const size_t tot = (size_t)n_e * n_f;
-    // the aperture in (depth, position) order — the order the predictor of the kernel wants; the coordinates are host memory
-    // here, so the sort is the host's: an aperture that arrives in that order (the usual case) goes through unchanged
     std::vector<int> order;
     std::vector<double> sx, sz;
-    bool sorted = true;
-    for (int i = 1; i < n_e && sorted; ++i) sorted = ze[i - 1] < ze[i] || (ze[i - 1] == ze[i] && xe[i - 1] <= xe[i]);
-    if (!sorted && !iters) {
-        order.resize(n_e);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ze[a] < ze[b] || (ze[a] == ze[b] && xe[a] < xe[b]); });
-        sx.resize(n_e); sz.resize(n_e);
-        for (int i = 0; i < n_e; ++i) { sx[i] = xe[order[i]]; sz[i] = ze[order[i]]; }
-    }
+    if (!iters) aperture_order(xe, ze, n_e, order, sx, sz);     // (the iteration counts are a diagnostic of the elements AS GIVEN)
     const bool perm = !order.empty();
     Session S;
     if ((st = S.open(device, 2 * al256(8 * (size_t)n_e) + 2 * al256(8 * (size_t)n_f) + al256(8 * tot) + (iters ? al256(tot) : 0) +
@@ -720,12 +759,18 @@ int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* 
     double* dtt = S.take<double>(tot);
     uint8_t* dit = iters ? S.take<uint8_t>(tot) : nullptr;
     HIP_TRY(S.flush());
-    if (perm) LAUNCH_TRY(rtus_launch_tt_layers_sorted(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, nullptr, drow, 0u, S.a->stream));
-    else LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, S.a->stream));
+    if (perm) LAUNCH_TRY(rtus_launch_tt_layers_sorted(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, nullptr, drow, flags, S.a->stream));
+    else LAUNCH_TRY(rtus_launch_tt_layers(z_if, c, n_if, dxe, dze, n_e, dxf, dzf, n_f, dtt, dit, flags, S.a->stream));
     S.download(tt, dtt, tot);
     S.download(iters, dit, tot);
     HIP_TRY(S.finish());
     return RTUS_OK;
+}
+
+int rtus_tt_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
+                   const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int device)
+{
+    return rtus_tt_layers_ex(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 0u, device);
 }
 
 // ---------------------------------------------------------------------------- consumers: focal laws, TFM
@@ -887,6 +932,35 @@ int rtus_tt_lens_f32_rows_dev(const rtus_lens* lens, double alpha_lo, double alp
     return RTUS_OK;
 }
 
+// How the lens table's rows were solved (diagnostic; tests/test_gpu_irregular_apertures.py): the same launch as
+// rtus_tt_lens[_f32]_rows_dev without the alpha output, plus five counters ADDED to d_stats (device memory, 5 x uint64, zeroed by
+// the caller), each in wave-elements (one wave = 64 targets of one row): [0] rows that took T alone at the extrapolated start,
+// [1] rows solved by one evaluation of T and g, [2] rows that needed the safeguarded iteration, [3] of those, rows that also
+// looked at the whole interval (a lane pinned at an end or nearly flat in alpha: two minima may compete), [4] evaluations spent in [2].
+int rtus_tt_lens_stats_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const double* d_xe, const double* d_ze, int n_rows,
+                           long long row0, long long n_rows_total, const double* d_xf, const double* d_zf, int n_f, double* d_tt,
+                           unsigned long long* d_stats, void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
+    if (!d_stats) return RTUS_ERR_INVALID_ARG;
+    LAUNCH_TRY(rtus_launch_tt_lens_f64(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt, nullptr, (int)row0,
+                                    n_rows_total, (hipStream_t)stream, d_stats));
+    return RTUS_OK;
+}
+
+int rtus_tt_lens_f32_stats_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* d_xe, const float* d_ze, int n_rows,
+                               long long row0, long long n_rows_total, const float* d_xf, const float* d_zf, int n_f, float* d_tt,
+                               unsigned long long* d_stats, void* stream)
+{
+    int st = check_lens(lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt);
+    if (st || (st = check_rows(n_rows, row0, n_rows_total))) return st;
+    if (!d_stats) return RTUS_ERR_INVALID_ARG;
+    LAUNCH_TRY(rtus_launch_tt_lens_f32(*lens, alpha_lo, alpha_hi, d_xe, d_ze, n_rows, d_xf, d_zf, n_f, d_tt, nullptr, (int)row0,
+                                    n_rows_total, (hipStream_t)stream, d_stats));
+    return RTUS_OK;
+}
+
 }   // extern "C" (the multi-device host entries share a template)
 
 // One host-buffer call spread over several devices: the table's rows in contiguous blocks (multiples of the table's rows per
@@ -899,16 +973,25 @@ static int table_multi(const R* xe, const R* ze, int n_e, const R* xf, const R* 
     if (!devices || n_dev <= 0 || n_dev > 64) return RTUS_ERR_INVALID_ARG;
     const long long per = rtus_shard_rows(n_e, n_f, (int)sizeof(R), n_dev);
     if (per < 0) return (int)per;
+    // The caller's current device comes back whatever the sessions do: this guard is declared before them, so it is the last to
+    // run (each session's own guard restores the device that was current when IT opened — the previous entry of the list).
+    DeviceGuard outer;
+    { int cur = -1; if (hipGetDevice(&cur) == hipSuccess) outer.prev = cur; }
     std::vector<Session> S(n_dev);
-    std::vector<int> live(n_dev, 0);
-    int st = RTUS_OK;
-    for (int i = 0; i < n_dev && st == RTUS_OK; ++i) {                 // uploads + launches: asynchronous on each device's stream
+    std::vector<int> live(n_dev, 0), slot(n_dev, 0), ord;
+    for (int i = 0; i < n_dev; ++i) {
+        for (int j = 0; j < i; ++j) slot[i] += devices[j] == devices[i];
         const long long lo = per * i < n_e ? per * i : n_e, hi = lo + per < n_e ? lo + per : n_e;
-        if (hi <= lo) continue;
-        int slot = 0;
-        for (int j = 0; j < i; ++j) slot += devices[j] == devices[i];
+        if (hi > lo) ord.push_back(i);
+    }
+    // arenas are locked in (device, slot) order, whatever the order of the list: two threads calling with [0, 1] and [1, 0]
+    // take the two mutexes in the same order
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return devices[a] != devices[b] ? devices[a] < devices[b] : slot[a] < slot[b]; });
+    int st = RTUS_OK;
+    for (int i : ord) {                                               // uploads + launches: asynchronous on each device's stream
+        const long long lo = per * i, hi = lo + per < n_e ? lo + per : n_e;
         const size_t rows = (size_t)(hi - lo), tot = rows * n_f;
-        if ((st = S[i].open(devices[i], 2 * al256(sizeof(R) * rows) + 2 * al256(sizeof(R) * (size_t)n_f) + al256(sizeof(R) * tot), slot))) break;
+        if ((st = S[i].open(devices[i], 2 * al256(sizeof(R) * rows) + 2 * al256(sizeof(R) * (size_t)n_f) + al256(sizeof(R) * tot), slot[i]))) break;
         R *dxe, *dze, *dxf, *dzf;
         S[i].upload(dxe, xe + lo, rows);
         S[i].upload(dze, ze + lo, rows);
@@ -924,9 +1007,13 @@ static int table_multi(const R* xe, const R* ze, int n_e, const R* xf, const R* 
     // results back: one host thread per device (a device-to-pageable-host copy occupies its caller; the links are independent)
     std::vector<hipError_t> err(n_dev, hipSuccess);
     std::vector<std::thread> th;
-    for (int i = 1; i < n_dev; ++i)
-        if (live[i]) th.emplace_back([&, i] { (void)hipSetDevice(S[i].dev_index); err[i] = S[i].finish(); });
-    if (live[0]) { (void)hipSetDevice(S[0].dev_index); err[0] = S[0].finish(); }
+    int mine = -1;
+    for (int i = 0; i < n_dev; ++i) {
+        if (!live[i]) continue;
+        if (mine < 0) { mine = i; continue; }
+        th.emplace_back([&, i] { (void)hipSetDevice(S[i].dev_index); err[i] = S[i].finish(); });
+    }
+    if (mine >= 0) { (void)hipSetDevice(S[mine].dev_index); err[mine] = S[mine].finish(); }
     for (auto& t : th) t.join();
     for (int i = 0; i < n_dev; ++i) if (st == RTUS_OK && err[i] != hipSuccess) st = hip_fail(err[i]);
     return st;
@@ -946,9 +1033,10 @@ struct Rccl {
     std::mutex mu;
     std::vector<int> devs;               // device list of the cached communicators
     std::vector<ncclComm_t> comms;
+    bool ok = false;                     // every symbol bound (a library that lacks one stays loaded and unused)
     bool load()
     {
-        if (h) return true;
+        if (h) return ok;
         for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
             if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!h) return false;
@@ -957,7 +1045,7 @@ struct Rccl {
         AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
         GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
-        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+        return ok = CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
     }
 };
 Rccl g_rccl;
@@ -989,15 +1077,20 @@ static int table_multi_dev(const R* const* d_xe, const R* const* d_ze, int n_e, 
     std::lock_guard<std::mutex> lk(g_rccl.mu);
     if (!g_rccl.load()) return RTUS_ERR_UNSUPPORTED;
     if (g_rccl.devs != std::vector<int>(devices, devices + n_dev)) {
-        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        // communicators of another device list: collectives of an earlier asynchronous call may still be queued on them
+        for (size_t k = 0; k < g_rccl.comms.size(); ++k) {
+            if (k < g_rccl.devs.size() && hipSetDevice(g_rccl.devs[k]) == hipSuccess) (void)hipDeviceSynchronize();
+            if (g_rccl.comms[k]) (void)g_rccl.CommDestroy(g_rccl.comms[k]);
+        }
         g_rccl.comms.assign(n_dev, nullptr);
         g_rccl.devs.clear();
         if (g_rccl.CommInitAll(g_rccl.comms.data(), n_dev, devices) != 0) { g_rccl.comms.clear(); return RTUS_ERR_UNSUPPORTED; }
         g_rccl.devs.assign(devices, devices + n_dev);
     }
     int bad = g_rccl.GroupStart();
+    if (bad) return RTUS_ERR_UNSUPPORTED;
     for (int i = 0; i < n_dev && !bad; ++i) {
-        HIP_TRY(hipSetDevice(devices[i]));
+        if (hipSetDevice(devices[i]) != hipSuccess) { bad = 1; break; }       // (the group is closed below on every path)
         bad = g_rccl.AllGather(d_tt[i] + (size_t)per * i * n_f, d_tt[i], (size_t)per * n_f, sizeof(R) == 8 ? kNcclFloat64 : kNcclFloat32,
                                g_rccl.comms[i], (hipStream_t)streams[i]);
     }
@@ -1007,14 +1100,31 @@ static int table_multi_dev(const R* const* d_xe, const R* const* d_ze, int n_e, 
 
 extern "C" {
 
+int rtus_tt_layers_multi_ex(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e, const double* xf,
+                            const double* zf, int n_f, double* tt, const int* devices, int n_dev, unsigned flags)
+{
+    int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
+    if (st || (st = check_tier(flags, nullptr))) return st;
+    // as the one-device twin: the aperture in (depth, position) order first, so that an element's bits do not depend on the order
+    // it was handed over in and the table is the one-device table whatever that order.  The shards are blocks of the SORTED rows;
+    // they come back into a staging table and every row is copied where it belongs.
+    std::vector<int> order;
+    std::vector<double> sx, sz, staged;
+    aperture_order(xe, ze, n_e, order, sx, sz);
+    const bool perm = !order.empty();
+    if (perm) staged.resize((size_t)n_e * n_f);
+    st = table_multi<double>(perm ? sx.data() : xe, perm ? sz.data() : ze, n_e, xf, zf, n_f, perm ? staged.data() : tt, devices, n_dev,
+                             [&](const double* dxe, const double* dze, int rows, int row0, const double* dxf, const double* dzf, double* dtt,
+                                 hipStream_t s) { return rtus_launch_tt_layers_rows(z_if, c, n_if, dxe, dze, rows, row0, n_e, dxf, dzf, n_f, dtt, flags, s); });
+    if (st == RTUS_OK && perm)
+        for (int i = 0; i < n_e; ++i) memcpy(tt + (size_t)order[i] * n_f, staged.data() + (size_t)i * n_f, sizeof(double) * (size_t)n_f);
+    return st;
+}
+
 int rtus_tt_layers_multi(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e, const double* xf,
                          const double* zf, int n_f, double* tt, const int* devices, int n_dev)
 {
-    int st = check_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt);
-    if (st) return st;
-    return table_multi<double>(xe, ze, n_e, xf, zf, n_f, tt, devices, n_dev,
-                               [&](const double* dxe, const double* dze, int rows, int row0, const double* dxf, const double* dzf, double* dtt,
-                                   hipStream_t s) { return rtus_launch_tt_layers_rows(z_if, c, n_if, dxe, dze, rows, row0, n_e, dxf, dzf, n_f, dtt, 0u, s); });
+    return rtus_tt_layers_multi_ex(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, devices, n_dev, 0u);
 }
 
 int rtus_tt_lens_f32_multi(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* xe, const float* ze, int n_e,
@@ -1029,17 +1139,24 @@ int rtus_tt_lens_f32_multi(const rtus_lens* lens, double alpha_lo, double alpha_
                               });
 }
 
+int rtus_tt_layers_multi_ex_dev(const double* z_if, const double* c, int n_if, const double* const* d_xe, const double* const* d_ze, int n_e,
+                                const double* const* d_xf, const double* const* d_zf, int n_f, double* const* d_tt, const int* devices,
+                                int n_dev, void* const* streams, int gather, unsigned flags)
+{
+    if (!d_xf || !d_zf || !d_xe || !d_ze || !d_tt || n_dev <= 0) return RTUS_ERR_INVALID_ARG;
+    int st = check_layers(z_if, c, n_if, d_xe[0], d_ze[0], n_e, d_xf[0], d_zf[0], n_f, d_tt[0]);
+    if (st || (st = check_tier(flags, nullptr))) return st;
+    return table_multi_dev<double>(d_xe, d_ze, n_e, n_f, d_tt, devices, n_dev, streams, gather,
+                                   [&](int i, const double* xe, const double* ze, int rows, int row0, double* tt, hipStream_t s) {
+                                       return rtus_launch_tt_layers_rows(z_if, c, n_if, xe, ze, rows, row0, n_e, d_xf[i], d_zf[i], n_f, tt, flags, s);
+                                   });
+}
+
 int rtus_tt_layers_multi_dev(const double* z_if, const double* c, int n_if, const double* const* d_xe, const double* const* d_ze, int n_e,
                              const double* const* d_xf, const double* const* d_zf, int n_f, double* const* d_tt, const int* devices,
                              int n_dev, void* const* streams, int gather)
 {
-    if (!d_xf || !d_zf || !d_xe || !d_ze || !d_tt || n_dev <= 0) return RTUS_ERR_INVALID_ARG;
-    int st = check_layers(z_if, c, n_if, d_xe[0], d_ze[0], n_e, d_xf[0], d_zf[0], n_f, d_tt[0]);
-    if (st) return st;
-    return table_multi_dev<double>(d_xe, d_ze, n_e, n_f, d_tt, devices, n_dev, streams, gather,
-                                   [&](int i, const double* xe, const double* ze, int rows, int row0, double* tt, hipStream_t s) {
-                                       return rtus_launch_tt_layers_rows(z_if, c, n_if, xe, ze, rows, row0, n_e, d_xf[i], d_zf[i], n_f, tt, 0u, s);
-                                   });
+    return rtus_tt_layers_multi_ex_dev(z_if, c, n_if, d_xe, d_ze, n_e, d_xf, d_zf, n_f, d_tt, devices, n_dev, streams, gather, 0u);
 }
 
 int rtus_tt_lens_f32_multi_dev(const rtus_lens* lens, double alpha_lo, double alpha_hi, const float* const* d_xe, const float* const* d_ze,

@@ -50,6 +50,7 @@ struct LayerArgs {
                                        // launch or in row shards
     // batched entry (rtus_tt_layers_batch): problem b = blockIdx.z uses elements / targets / output shifted by these
     long long e_stride, f_stride, t_stride;   // in elements of the respective arrays (0: shared by all problems)
+    int gx, gy, n_items;               // work items: gx columns of 256 targets x gy blocks of rows (x n_batch problems) = n_items
 };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -162,7 +163,7 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
 // TAUP: the travel time from the tau-p form T = p X + sum (h_i / c_i) cos(theta_i) instead of T(q) + its Fermat expansion — see
 // the tail below.
 template <int NL, bool ITERS, bool FAST, bool TAUP>
-__device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, const ElemRec& R, int hist, double xf,
+__device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL>& L, const ElemRec& R, int hist, double xf,
                                             float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f,
                                             __amdgpu_buffer_rsrc_t rs, unsigned soff)
 {
@@ -289,7 +290,7 @@ __device__ __forceinline__ float solve_elem(const LayerArgs& a, Lane<NL>& L, con
     {
         const u32x2 bits = {(unsigned)__double2loint(T), (unsigned)__double2hiint(T)};
         __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, soff, 0);
-        if (ITERS && live) (a.iters + row)[f] = (uint8_t)it;
+        if (ITERS && live) (iters + row)[f] = (uint8_t)it;
     }
     // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
     const float qroot = q + dq;
@@ -310,17 +311,31 @@ template <int NL, bool ITERS, bool TAUP = false, bool PERM = false>
 __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_tt_layers_kernel(LayerArgs a)
 {
     __shared__ ElemRec rec[64];
-    // batched launch: problem blockIdx.z
-    a.xe += (size_t)blockIdx.z * a.e_stride; a.ze += (size_t)blockIdx.z * a.e_stride;
-    a.xf += (size_t)blockIdx.z * a.f_stride; a.zf += (size_t)blockIdx.z * a.f_stride;
-    a.tt += (size_t)blockIdx.z * a.t_stride;
-    if (ITERS) a.iters += (size_t)blockIdx.z * a.t_stride;
+    // Work items = (column of 256 targets, block of rows, problem of a batch): one per workgroup.  -DRTUS_EXP_PERSIST (experiment
+    // builds only, scripts/gpu_planar_r04.sh) runs them as a PERSISTENT grid instead — 8 workgroups per CU, workgroup w takes items
+    // w, w + gridDim.x, ... — to find out whether the half-empty wave slots between the two rounds of a configs[2] launch cost time:
+    // they do not (round 4: slots full, launch 1-2 % SLOWER) — the kernel is bound by VALU issue, not by residency.
+#ifdef RTUS_EXP_PERSIST
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    const int bx = item % a.gx, byz = item / a.gx, by = byz % a.gy, bz = byz / a.gy;
+    if (item != (int)blockIdx.x) __syncthreads();           // the previous item's records are still being read by the slower waves
+#else
+    {
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#endif
+    // batched launch: problem bz
+    const double* __restrict__ xe_p = a.xe + (size_t)bz * a.e_stride;
+    const double* __restrict__ ze_p = a.ze + (size_t)bz * a.e_stride;
+    const double* __restrict__ xf_p = a.xf + (size_t)bz * a.f_stride;
+    const double* __restrict__ zf_p = a.zf + (size_t)bz * a.f_stride;
+    double* __restrict__ tt_p = a.tt + (size_t)bz * a.t_stride;
+    uint8_t* __restrict__ it_p = ITERS ? a.iters + (size_t)bz * a.t_stride : nullptr;
 
-    const int f_raw = blockIdx.x * RTUS_BLOCK + threadIdx.x;
+    const int f_raw = bx * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
-    const double xf = a.xf[f], zf = a.zf[f];
-    const int gb = a.row0 / a.eb + blockIdx.y;              // the workgroup's block of the whole table
+    const double xf = xf_p[f], zf = zf_p[f];
+    const int gb = a.row0 / a.eb + by;                      // the workgroup's block of the whole table
     const int e0 = max(gb * a.eb - a.row0, 0);              // ... in this launch's rows (a shard that starts inside a block keeps its tail)
     const int ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;   // elements of this workgroup (<= 64)
 
@@ -329,9 +344,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         const int lane = threadIdx.x;
         const int el = min(e0 + lane, a.n_e - 1);
         const int b1 = max(el - 1, e0), b2 = max(el - 2, e0), b3 = max(el - 3, e0), b4 = max(el - 4, e0);
-        const double x0 = a.xe[el], z0 = a.ze[el];
-        const double x1 = a.xe[b1], x2 = a.xe[b2], x3 = a.xe[b3], x4 = a.xe[b4];
-        const double z1 = a.ze[b1], z2 = a.ze[b2], z3 = a.ze[b3], z4 = a.ze[b4];     // all loads issued together
+        const double x0 = xe_p[el], z0 = ze_p[el];
+        const double x1 = xe_p[b1], x2 = xe_p[b2], x3 = xe_p[b3], x4 = xe_p[b4];
+        const double z1 = ze_p[b1], z2 = ze_p[b2], z3 = ze_p[b3], z4 = ze_p[b4];     // all loads issued together
         // how many predecessors inside this workgroup share the element's depth (the history restarts when ze changes)
         const bool s1 = (lane >= 1) & (z1 == z0), s2 = s1 & (lane >= 2) & (z2 == z0), s3 = s2 & (lane >= 3) & (z3 == z0),
                    s4 = s3 & (lane >= 4) & (z4 == z0);
@@ -365,6 +380,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         const unsigned long long rest = ~(m4 >> lane);
         const int run = (m == 4 && lane < ne) ? (rest ? __ffsll((long long)rest) - 1 : 64 - lane) : 0;
         ElemRec r;
+#ifdef RTUS_EXP_BAD_PREDICTOR                               // experiment builds only (scripts/selftest_predictor.sh): the continuation tests must notice
+        w1 *= 1.02f; w3 *= 0.97f;
+#endif
         r.w1 = w1; r.w2 = w2; r.w3 = w3; r.w4 = w4; r.xe = x0;
         r.info = m | (hist == 0 ? 8 : 0) | (run << 8);
         r.row = PERM ? a.row_of[el] : 0;
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     const size_t nf = (size_t)a.n_f;
     size_t o = (size_t)e0 * nf;                              // output row of element e0 + li (wave-uniform; ITERS only)
     const unsigned row_bytes = (unsigned)a.n_f * 8u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.tt + o, 0, (unsigned)ne * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tt_p + o, 0, (unsigned)ne * row_bytes, 0x00020000);
     unsigned so = 0;                                         // li * row_bytes (< 2^32: the launcher sizes eb for it)
     int li = 0;
     // where element `idx` of the block is stored: its row inside the workgroup's block of rows (one descriptor, the row as the
@@ -388,13 +406,13 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     auto dest_o = [&](int idx, size_t off) { return PERM ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[idx].row) * nf : off; };
     auto dest_rs = [&](int idx, size_t off) {
         if (!PERM) return rs;
-        return __builtin_amdgcn_make_buffer_rsrc(a.tt + dest_o(idx, off), 0, row_bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(tt_p + dest_o(idx, off), 0, row_bytes, 0x00020000);
     };
     auto dest_so = [&](unsigned off) { return PERM ? 0u : off; };
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
         if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
-            layer_setup<NL>(a, a.ze[e0 + li], zf, L);
+            layer_setup<NL>(a, ze_p[e0 + li], zf, L);
             qa = qb = qc = qd = 0.0f;                        // a lane may carry NaN history from a depth at which its target
                                                              // was not below the element
         }
@@ -402,20 +420,21 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         if (run4 > 0) {
             // four-history run, unrolled by four so that the history rotates through its registers without moves
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
-                qc = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
-                qb = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
-                qa = solve_elem<NL, ITERS, true, TAUP>(a, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                qd = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
+                qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
                 o += 4 * nf; so += 4 * row_bytes;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false, TAUP>(a, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
+            const float qn = solve_elem<NL, ITERS, false, TAUP>(it_p, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf; so += row_bytes;
             ++li;
         }
     }
+    }   // items
 }
 
 // Order of the aperture.  The predictor extrapolates from the four previous elements of a workgroup's block, which only works when
@@ -488,7 +507,20 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     if (eb < 1 || (n_rows_total + eb - 1) / eb > 65535) return hipErrorInvalidValue;
     a.row0 = row0;
     a.eb = eb;
-    const dim3 grid((n_f + RTUS_BLOCK - 1) / RTUS_BLOCK, (row0 + n_e - 1) / eb - row0 / eb + 1, n_batch), block(RTUS_BLOCK);
+    a.gx = (n_f + RTUS_BLOCK - 1) / RTUS_BLOCK; a.gy = (row0 + n_e - 1) / eb - row0 / eb + 1;
+    const long long items = (long long)a.gx * a.gy * n_batch;
+    if (items > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.n_items = (int)items;
+#ifdef RTUS_EXP_PERSIST                                      // experiment builds only: see the kernel
+    long long cap = items;
+    if (n_if + 1 <= 3 && !iters) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cap = 8LL * n;
+    }
+    const dim3 grid((unsigned)(items < cap ? items : cap)), block(RTUS_BLOCK);
+#else
+    const dim3 grid(a.gx, a.gy, n_batch), block(RTUS_BLOCK);
+#endif
 #ifdef RTUS_EXP_TAUP_DEFAULT                                // experiment builds only (scripts/ab_planar.py)
     flags |= RTUS_TT_TAUP_TAIL;
 #endif
@@ -509,9 +541,9 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
 
 hipError_t rtus_launch_tt_layers(const double* z_if, const double* c, int n_if, const double* xe,
                                  const double* ze, int n_e, const double* xf, const double* zf, int n_f,
-                                 double* tt, uint8_t* iters, hipStream_t s)
+                                 double* tt, uint8_t* iters, unsigned flags, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, 0, n_e, 0u, nullptr, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, iters, 1, 0, 0, 0, 0, n_e, flags, nullptr, s);
 }
 
 // rows [row0, row0 + n_e) of a table of n_rows_total rows: the same bits as the whole table's launch gives those rows when
@@ -527,9 +559,9 @@ hipError_t rtus_launch_tt_layers_rows(const double* z_if, const double* c, int n
 // problem b reads xe/ze + b e_stride, xf/zf + b f_stride and writes tt + b t_stride.
 hipError_t rtus_launch_tt_layers_batch(const double* z_if, const double* c, int n_if, const double* xe, const double* ze,
                                        int n_e, long long e_stride, const double* xf, const double* zf, int n_f,
-                                       long long f_stride, double* tt, long long t_stride, int n_batch, hipStream_t s)
+                                       long long f_stride, double* tt, long long t_stride, int n_batch, unsigned flags, hipStream_t s)
 {
-    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, 0, n_e, 0u, nullptr, s);
+    return launch_layers(z_if, c, n_if, xe, ze, n_e, xf, zf, n_f, tt, nullptr, n_batch, e_stride, f_stride, t_stride, 0, n_e, flags, nullptr, s);
 }
 
 // The whole table with the aperture in ANY order: sorted copies of the coordinates + each element's row in `ws`

@@ -43,7 +43,10 @@ template <typename R> struct LensFermatArgs {
     int n_e, n_f, eb;
     int row0;                // index of xe[0] in the whole table (row shards: workgroups stay aligned to the table's blocks, see rtus_fermat.hip)
     int poly_trig;           // 1: [a_lo, a_hi] lies inside [-1, 1] rad -> sin/cos by polynomial, no range reduction
-    R gp_min, gp_dx;         // a lane whose g' at its minimum is below gp_min + gp_dx |x_e - x_full| may have a second minimum (kernel comment)
+    R gp_min, gp_dx;         // a lane whose g' at its minimum is below gp_min (+ gp_dx x the block's reach) may have a second minimum (kernel comment)
+    unsigned long long* __restrict__ stats;   // nullable (rtus_tt_lens*_stats_dev): per wave-element, how it was solved —
+                                              // [0] T alone at the extrapolated start, [1] one evaluation (lite step), [2] the safeguarded
+                                              // iteration, [3] of those: with a scan of the whole interval, [4] evaluations inside [2]
 };
 
 template <typename R> __device__ __forceinline__ R rsqrt_r(R v);
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         r.xa = xe_v; r.za = ze_v;
         r.w1 = quad ? q1 : (lin ? t2 * r12 : 0.0f);
         r.w3 = quad ? q3 : 0.0f;
+#ifdef RTUS_EXP_BAD_PREDICTOR                               // experiment builds only (scripts/selftest_predictor.sh): the continuation tests must notice
+        r.w1 *= 1.05f; r.w3 *= 0.9f;
+#endif
         r.mode = lin ? 2 : (hist >= 1 ? 1 : 0);
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(r.mode == 2 && idx < ne);
         float xmn = (float)xe_v, xmx = (float)xe_v;          // (idx >= ne repeats the last element: no effect on the extent)
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
     unsigned soff = 0;                                       // li * row_bytes
 
     unsigned long long rgp_bad = ~0ull;                      // lanes whose rgp is not usable (wave-uniform mask: the test is one scalar compare)
+    int n_tonly = 0, n_lite = 0, n_full = 0, n_scan = 0, n_trip = 0;   // wave-uniform tallies for a.stats (scalar adds)
 
     // WHEN THE MINIMUM FOLLOWED FROM ELEMENT TO ELEMENT MAY NOT BE THE LEAST TIME.  The lens is aplanatic: for a target at its
     // focus T(alpha) is constant, around the focus it is nearly flat, and an off-axis element can then have TWO local minima (an
@@ -305,12 +312,12 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
     // follows one of them; the table entry is the lesser (Fermat).  Measured on the CPU over the water below the reference lens
     // (elements within +-20 mm, 4,001 samples of alpha per pair): wherever a pair has more than one local
     // minimum, g' at every INTERIOR one is <= 3.7e-6 s/rad^2, against >= 3e-5 on tables away from the focus (BASELINE configs[3]:
-    // 2.9e-5 ... 2.3e-4).  So a lane is SUSPECT when its minimum is pinned at an end of the interval or its g' there is below
-    // gp_min (= 1.5e-5 for the reference lens: four times the bound): the generic step then looks at the whole interval (`scan`).
-    // The fast rows below do not evaluate g'; it moves by <= 1.2e-3 s/rad^2 per metre of element position along the followed
-    // minimum, so they run only while the latest full evaluation says g' >= gp_min + gp_dx * (the farthest any element of the block
-    // is from that one) in every lane: no element of the block can be suspect then.  Not suspect => one minimum => the
-    // continuation is right.
+    // 2.9e-5 ... 2.3e-4; targets 1 cm from the focus: ~5e-6 ... 1.2e-5).  So a lane is SUSPECT when its minimum is pinned at an end
+    // of the interval or its g' there is below gp_min (= 7.5e-6 for the reference lens: twice the bound): the generic step then looks
+    // at the whole interval (`scan`).  The fast rows below do not evaluate g'; along the followed minimum it moves by 1.5 ... 2.6e-4
+    // s/rad^2 per metre of element position (faster only where it is below gp_min anyway), so they run only while the latest full
+    // evaluation says g' >= gp_min + gp_dx * (the farthest any element of the block is from that one) in every lane, gp_dx = 3.9e-4:
+    // no element of the block can be suspect then.  Not suspect => one minimum => the continuation is right.
     const R gp_min = a.gp_min, gp_dx = a.gp_dx;              // (only the generic step reads them: scalar operands will do)
     unsigned long long flat_ahead = ~0ull;                   // lanes whose g' could fall below gp_min before the block ends (wave-uniform mask)
 
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         LDBG(2);
         if (big) { miss = step; return false; }              // (the generic step starts its iteration one Newton step on: `miss`)
         LDBG(3);
+        n_lite += 1;
         miss = step;
         store_at<R>(rs_t, voff, soff, T + R(0.5) * g * step);    // T(a*) = T(a) - g^2 / (2 g')
         if (WA) store_at<R>(rs_a, voff, soff, alpha + step);
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         const R alpha = fmin(fmax(n1 + ((R)(w1 - 1.0f) * (n1 - n2) + (R)w3 * (n3 - n2)), a_lo), a_hi);
         store_at<R>(rs_t, voff, soff, lens_time_only<R, POLY>(k, alpha, xa, za, xf, zf));
         soff += row_bytes;
+        n_tonly += 1;
         n3 = alpha;
     };
 
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         bool done = false;
         for (int trip = 0; trip < 80; ++trip) {
             LDBG(6);
+            n_trip += 1;
             lens_time<R, true, POLY>(k, alpha, xa_cur, za_cur, xf, zf, T, g, gp);
             if (g > R(0)) hi = alpha; else lo = alpha;
             R step = -g * rcp_r<R>(gp);
@@ -471,6 +481,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
             took_lite = true;
             if (!big) {
                 LDBG(3);
+                n_lite += 1;
                 T += R(0.5) * g * step;
                 alpha += step;
                 hist_fix(step);
@@ -479,6 +490,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         }
         if (!one) {
             LDBG(4);
+            n_full += 1;
             // the fast rows' failed lite step (or the one just above) has evaluated `start` already: the iteration begins one
             // Newton step on (with the previous element's g': iterate() takes it from there, inside the interval)
             alpha = fmin(fmax(start + (took_lite ? miss : R(0)), a_lo), a_hi);
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
             const bool sus = !(gpl >= gp_min);               // pinned, NaN, or flat enough for a second minimum to exist
             if (__builtin_amdgcn_ballot_w64(sus)) {          // wave-uniform
                 LDBG(5);
+                n_scan += 1;
                 R bA = alpha, bT = T;
                 bool moved = false;
                 scan(bA, bT, moved);
@@ -562,13 +575,18 @@ __global__ __launch_bounds__(RTUS_BLOCK, sizeof(R) == 4 ? 8 : 3) void rtus_tt_le
         generic(li, mode, !left);
         ++li;
     }
+    if (a.stats && lane == 0) {                              // (null in every product call)
+        atomicAdd(a.stats + 0, (unsigned long long)n_tonly); atomicAdd(a.stats + 1, (unsigned long long)n_lite);
+        atomicAdd(a.stats + 2, (unsigned long long)n_full); atomicAdd(a.stats + 3, (unsigned long long)n_scan);
+        atomicAdd(a.stats + 4, (unsigned long long)n_trip);
+    }
 }
 
 int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_bytes);   // rtus_fermat.hip
 
 template <typename R>
 static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, const R* xe, const R* ze, int n_e,
-                              const R* xf, const R* zf, int n_f, R* tt, R* alpha_out, int row0, long long n_rows_total, hipStream_t s)
+                              const R* xf, const R* zf, int n_f, R* tt, R* alpha_out, int row0, long long n_rows_total, unsigned long long* stats, hipStream_t s)
 {
     const LensK kk = make_lens_k(L);
     LensFermatArgs<R> k;
@@ -576,10 +594,12 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
     k.phi_3 = (R)kk.phi_3; k.twoTc = (R)kk.twoTc; k.C4A = (R)kk.C4A; k.inv2A = (R)(1.0 / kk.twoA);
     k.a_lo = (R)a_lo; k.a_hi = (R)a_hi;
     k.xe = xe; k.ze = ze; k.xf = xf; k.zf = zf; k.tt = tt; k.alpha_out = alpha_out;
-    k.n_e = n_e; k.n_f = n_f;
+    k.n_e = n_e; k.n_f = n_f; k.stats = stats;
     k.poly_trig = (a_lo >= -1.0 && a_hi <= 1.0) ? 1 : 0;
-    // the lens's own time and speed scale the two constants measured on the reference lens (h0 / c2 = 5.96e-5 s: 1.5e-5 and 2e-3)
-    k.gp_min = (R)(0.25 * L.h0 / L.c2); k.gp_dx = (R)(3.0 / L.c2);
+    // the lens's own time and speed scale the two constants measured on the reference lens: 7.5e-6 s/rad^2 (twice the largest g' seen
+    // at an interior minimum of a pair with two minima; h0 / c2 = 5.96e-5 s) and 3.9e-4 s/rad^2 per metre (g' at the followed minimum
+    // moves by 1.5 ... 2.6e-4 per metre of element position wherever it is above that — 1 / c1 = 1.56e-4 —, faster only next to the focus)
+    k.gp_min = (R)(0.125 * L.h0 / L.c2); k.gp_dx = (R)(2.5 / L.c1);
     k.eb = rtus_rows_per_block(n_rows_total, n_f, 1, (int)sizeof(R));   // of the WHOLE table: row shards reproduce its bits
     if (k.eb < 1 || (n_rows_total + k.eb - 1) / k.eb > 65535) return hipErrorInvalidValue;
     k.row0 = row0;
@@ -594,14 +614,14 @@ static hipError_t launch_lens(const rtus_lens& L, double a_lo, double a_hi, cons
 
 hipError_t rtus_launch_tt_lens_f64(const rtus_lens& L, double a_lo, double a_hi, const double* xe, const double* ze,
                                    int n_e, const double* xf, const double* zf, int n_f, double* tt,
-                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s)
+                                   double* alpha_out, int row0, long long n_rows_total, hipStream_t s, unsigned long long* stats)
 {
-    return launch_lens<double>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, s);
+    return launch_lens<double>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, stats, s);
 }
 
 hipError_t rtus_launch_tt_lens_f32(const rtus_lens& L, double a_lo, double a_hi, const float* xe, const float* ze,
                                    int n_e, const float* xf, const float* zf, int n_f, float* tt, float* alpha_out,
-                                   int row0, long long n_rows_total, hipStream_t s)
+                                   int row0, long long n_rows_total, hipStream_t s, unsigned long long* stats)
 {
-    return launch_lens<float>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, s);
+    return launch_lens<float>(L, a_lo, a_hi, xe, ze, n_e, xf, zf, n_f, tt, alpha_out, row0, n_rows_total, stats, s);
 }

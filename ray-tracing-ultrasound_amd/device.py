@@ -167,17 +167,17 @@ def tt_layers_dev(z_if, c, xe, ze, xf, zf, out=None, iters=None, row0=0, n_rows_
     _chk(out, "out")
     if out.numel() != n_e * n_f:
         raise ValueError("out has the wrong size")
-    if n_rows_total is not None or taup:
-        if iters is not None:
-            raise ValueError("iters is a whole-table diagnostic of the accurate tier")
+    if iters is not None and (n_rows_total is not None or taup):
+        raise ValueError("iters is a whole-table diagnostic of the accurate tier")
+    if n_rows_total is not None:
         st = _lib.lib().rtus_tt_layers_rows_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
                                                 n_e, int(row0), int(n_e if n_rows_total is None else n_rows_total), _p(xf), _p(zf), n_f,
                                                 _p(out), TAUP_TAIL if taup else 0, _stream())
         _lib.check(st, "rtus_tt_layers_rows_dev")
         return out
-    st = _lib.lib().rtus_tt_layers_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
-                                       _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), _stream())
-    _lib.check(st, "rtus_tt_layers_dev")
+    st = _lib.lib().rtus_tt_layers_ex_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe),
+                                          _p(ze), n_e, _p(xf), _p(zf), n_f, _p(out), _p(iters), TAUP_TAIL if taup else 0, _stream())
+    _lib.check(st, "rtus_tt_layers_ex_dev")
     return out
 
 
@@ -235,8 +235,30 @@ def tt_lens_rows_dev(xe, ze, xf, zf, out, *, params: Params = None, alpha_lo=Non
     return out
 
 
-def tt_layers_batch_dev(z_if, c, xe, ze, xf, zf, out=None):
-    """B independent problems of one shape and one medium in ONE launch (rtus_tt_layers_batch_dev).
+def tt_lens_stats_dev(xe, ze, xf, zf, out, *, params: Params = None, alpha_lo=None, alpha_hi=None, row0=0, n_rows_total=None):
+    """tt_lens_rows_dev + how the rows were solved (rtus_tt_lens[_f32]_stats_dev) -> (out, dict of wave-element counts)."""
+    from .api import ALPHA_MAX
+    p = _resolve(params)
+    f64 = xe.dtype == torch.float64
+    for t, n in ((xe, "xe"), (ze, "ze"), (xf, "xf"), (zf, "zf"), (out, "out")):
+        _chk(t, n, xe.dtype)
+    n_e, n_f = xe.numel(), xf.numel()
+    if ze.numel() != n_e or zf.numel() != n_f or out.numel() != n_e * n_f:
+        raise ValueError("xe/ze, xf/zf and out must pair up")
+    stats = torch.zeros(5, dtype=torch.int64, device=xe.device)
+    fn = _lib.lib().rtus_tt_lens_stats_dev if f64 else _lib.lib().rtus_tt_lens_f32_stats_dev
+    lens = p.lens()
+    st = fn(C.byref(lens), -ALPHA_MAX if alpha_lo is None else float(alpha_lo), ALPHA_MAX if alpha_hi is None else float(alpha_hi),
+            _p(xe), _p(ze), n_e, int(row0), int(n_e if n_rows_total is None else n_rows_total), _p(xf), _p(zf), n_f, _p(out), _p(stats),
+            _stream())
+    _lib.check(st, "rtus_tt_lens_stats_dev")
+    v = [int(x) for x in stats.cpu()]
+    return out, dict(t_only=v[0], one_evaluation=v[1], iterated=v[2], scanned=v[3], iteration_evaluations=v[4],
+                     wave_elements=n_e * 4 * ((n_f + 255) // 256))     # waves launched per row: whole workgroups of 256 targets
+
+
+def tt_layers_batch_dev(z_if, c, xe, ze, xf, zf, out=None, taup=False):
+    """B independent problems of one shape and one medium in ONE launch (rtus_tt_layers_batch_ex_dev; taup: the faster accuracy tier).
 
     xe/ze: [B, n_e] or [n_e] (one aperture shared by all problems); xf/zf: [B, n_f] or [n_f] (shared) -> tt [B, n_e, n_f].
     At least one of the two must carry the batch dimension."""
@@ -258,10 +280,10 @@ def tt_layers_batch_dev(z_if, c, xe, ze, xf, zf, out=None):
     _chk(out, "out")
     if out.numel() != B * n_e * n_f:
         raise ValueError("out has the wrong size")
-    st = _lib.lib().rtus_tt_layers_batch_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
-                                             n_e, n_e if xe.dim() == 2 else 0, _p(xf), _p(zf), n_f,
-                                             n_f if xf.dim() == 2 else 0, _p(out), n_e * n_f, B, _stream())
-    _lib.check(st, "rtus_tt_layers_batch_dev")
+    st = _lib.lib().rtus_tt_layers_batch_ex_dev(z_if.ctypes.data if z_if.size else None, c.ctypes.data, z_if.size, _p(xe), _p(ze),
+                                                n_e, n_e if xe.dim() == 2 else 0, _p(xf), _p(zf), n_f,
+                                                n_f if xf.dim() == 2 else 0, _p(out), n_e * n_f, B, TAUP_TAIL if taup else 0, _stream())
+    _lib.check(st, "rtus_tt_layers_batch_ex_dev")
     return out
 
 

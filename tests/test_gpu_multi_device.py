@@ -112,6 +112,9 @@ def test_multi_dev_variant_two_shards_left_sharded(rtus):
                                     xf.size, arr(tabs), (C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)(*[s.cuda_stream for s in streams]), 1)
     torch.cuda.synchronize()
     assert st in (0, -5)                                             # RTUS_ERR_UNSUPPORTED (no librccl / duplicate devices) or a working RCCL
+    if st == 0:                                                      # an exchange took place: every copy must hold the whole table
+        for tab in tabs:
+            assert np.array_equal(tab[:150].cpu().numpy(), one)
     # the fp32 lens table the same way
     n_e = 150
     xl, zl = np.meshgrid(np.linspace(-0.004, 0.004, 256), np.linspace(0.03, 0.07, 128))
@@ -127,3 +130,71 @@ def test_multi_dev_variant_two_shards_left_sharded(rtus):
     torch.cuda.synchronize()
     one32 = rtus.travel_time_lens(xe32.cpu().numpy(), ze32.cpu().numpy(), xl.ravel(), zl.ravel(), params=rtus.Params(), dtype=np.float32)
     assert np.array_equal(tabs32[0][:per32].cpu().numpy(), one32[:per32]) and np.array_equal(tabs32[1][per32:n_e].cpu().numpy(), one32[per32:])
+
+
+def test_tier_reaches_every_planar_entry(rtus):
+    """RTUS_TT_TAUP_TAIL (the tier bench.py's headline times) through the NumPy call, the device-pointer call, the batch call and the
+    several-GPU calls: all the same bits as rtus_tt_layers_rows_dev gives with the flag, and not the default tier's."""
+    import torch
+    from importlib import import_module
+    dev = import_module("ray-tracing-ultrasound_amd.device")
+    z_if, c, xe, ze, xf, zf = _planar(150, 144)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    ref = dev.tt_layers_dev(z_if, c, t(xe), t(ze), t(xf), t(zf), row0=0, n_rows_total=150, taup=True).cpu().numpy()
+    acc = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)
+    assert not np.array_equal(ref, acc) and np.max(np.abs(ref - acc) / acc) < 1e-10
+    assert np.array_equal(rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, taup=True), ref)
+    assert np.array_equal(rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, taup=True, devices=[0, 0]), ref)
+    assert np.array_equal(dev.tt_layers_dev(z_if, c, t(xe), t(ze), t(xf), t(zf), taup=True).cpu().numpy(), ref)
+    both = dev.tt_layers_batch_dev(z_if, c, t(xe), t(ze), torch.stack([t(xf), t(xf)]), torch.stack([t(zf), t(zf)]), taup=True).cpu().numpy()
+    # (a batch of two sizes its workgroups for both problems together: compare with the batch's own default tier instead of bits)
+    both_acc = dev.tt_layers_batch_dev(z_if, c, t(xe), t(ze), torch.stack([t(xf), t(xf)]), torch.stack([t(zf), t(zf)])).cpu().numpy()
+    assert np.array_equal(both[0], both[1]) and not np.array_equal(both, both_acc) and np.max(np.abs(both - both_acc) / both_acc) < 1e-10
+    with pytest.raises(ValueError):
+        rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, taup=True, return_iters=True)
+    iters = np.empty((150, xf.size), dtype=np.uint8)
+    st = rtus.lib().rtus_tt_layers_ex(np.asarray(z_if).ctypes.data, np.asarray(c).ctypes.data, 2, xe.ctypes.data, ze.ctypes.data, 150, xf.ctypes.data,
+                                      zf.ctypes.data, xf.size, acc.ctypes.data, iters.ctypes.data, 1, 0)
+    assert st == -1                                                  # RTUS_ERR_INVALID_ARG: the iteration counts belong to the default tier
+    # the multi_dev entry
+    per = int(rtus.lib().rtus_shard_rows(150, xf.size, 8, 2))
+    tabs = [torch.full((2 * per, xf.size), -1.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    txe, tze, txf, tzf = t(xe), t(ze), t(xf), t(zf)
+    arr = lambda ts: (C.c_void_p * 2)(*[x.data_ptr() for x in ts])
+    zi, cc = np.asarray(z_if, dtype=np.float64), np.asarray(c, dtype=np.float64)
+    st = rtus.lib().rtus_tt_layers_multi_ex_dev(zi.ctypes.data, cc.ctypes.data, 2, arr([txe, txe]), arr([tze, tze]), 150, arr([txf, txf]), arr([tzf, tzf]),
+                                                xf.size, arr(tabs), (C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)(*[s.cuda_stream for s in streams]), 0, 1)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(tabs[0][:per].cpu().numpy(), ref[:per]) and np.array_equal(tabs[1][per:150].cpu().numpy(), ref[per:])
+
+
+def test_layers_multi_unsorted_aperture_is_the_one_device_table(rtus):
+    """The several-GPU host call sorts the aperture as the one-device call does: shuffled elements, depth steps and
+    duplicates give the one-device table bit for bit, and each row equals the row of the ordered aperture."""
+    rng = np.random.default_rng(3)
+    z_if, c, xe, ze, xf, zf = _planar(150, 144)
+    ze = np.repeat([0.0, 0.0005, 0.001], 50)
+    order = rng.permutation(150)
+    one = rtus.travel_time_layers(z_if, c, xe[order], ze[order], xf, zf)
+    many = rtus.travel_time_layers(z_if, c, xe[order], ze[order], xf, zf, devices=[0, 0])
+    assert np.array_equal(one, many)
+    assert np.array_equal(one, rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)[order])
+    dup = np.concatenate([order[:75], order[:75]])
+    assert np.array_equal(rtus.travel_time_layers(z_if, c, xe[dup], ze[dup], xf, zf, devices=[0, 0, 0]),
+                          rtus.travel_time_layers(z_if, c, xe[dup], ze[dup], xf, zf))
+
+
+def test_multi_leaves_the_callers_device_current(rtus):
+    """rtus_*_multi open one session per listed device; the caller's current device must come back.  One GPU here:
+    the current device is 0 before and after, and a following torch launch lands on it."""
+    import torch
+    a = _planar(37, 24)
+    before = torch.cuda.current_device()
+    rtus.travel_time_layers(*a, devices=[0, 0, 0])
+    dev_now = C.c_int(-1)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipGetDevice(C.byref(dev_now)) == 0 and dev_now.value == before == torch.cuda.current_device()
+    assert float(torch.ones(4, device="cuda").sum()) == 4.0
