@@ -250,8 +250,8 @@ class Timed:
 
 
 def load_profile_json(name):
-    """profiles/<name>: the newest round's file wins (r03 over r02 over r01)."""
-    for tag in ("r03", "r02", "r01"):
+    """profiles/<name>: the newest round's file wins (r04 over r03 over ...)."""
+    for tag in ("r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", name.format(tag=tag))
         if os.path.exists(p):
             try:
@@ -471,6 +471,15 @@ def main(argv=None):
     if gather_error is not None:
         out["reassembly"] = {"collective": "all_gather_into_tensor (RCCL)", "error": gather_error}
     if world > 1:
+        # what `value` is, where nobody can overlook it: the solves alone; the table's reassembly is timed beside it
+        out["value_basis"] = ("collective-free" if (gather_after or args.gather == "off") else
+                              "with the all-gather of the final table" if gather_end else "with an all-gather every step")
+        rs = out.get("value_with_reassembly")
+        out["config"]["numerics"] = (f"VALUE = {out['value']} Mrays/s is the COLLECTIVE-FREE solve rate; with ONE RCCL all-gather of the table after the "
+                                     f"K steps: {rs} Mrays/s (value_with_reassembly), reassembled every step: {out.get('value_reassembled_every_step')} "
+                                     f"Mrays/s — the table's reassembly, not the solve, decides those (DESIGN.md section 6); the workload that "
+                                     f"scales WITH its collective inside the timed region is extra.tfm_columns.  " + out["config"]["numerics"])
+    if world > 1:
         out["multi_gpu_note"] = ("RCCL over xGMI first ran in the driver's scaling job (the build pool has one GPU per box); compare "
                                  "this line with `extra.cfg4_lens_f32_full` (the same table on one GPU) of the N = 1 line" if wl == "cfg4_lens_f32"
                                  else "per-GPU work fixed (weak scaling): no data-path collective")
@@ -505,16 +514,64 @@ def main(argv=None):
             out["max_abs_dt_s"] = acc["max_abs_dt_s"]
     if rank == 0 and world == 1 and not args.no_extra and wl == "cfg3_planar":
         out["extra"] = extra_measurements(dev_api, dist_api, rtus, t64, torch, dev)
+        lens_samples = out["extra"].pop("_lens_samples", {})
         if not args.no_cpu_baseline:
             out["extra"]["cpu_ref_path"] = cpu_ref_path()
+            out["extra"]["lens_tables_accuracy"] = lens_tables_accuracy(lens_samples)
     if world > 1 and not args.no_extra and wl == "cfg4_lens_f32" and args.gather != "step":
         fm = fmc_strong(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args)
+        tc = tfm_columns(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args)
         if rank == 0:
-            out["extra"] = {"cfg5_fmc": fm}
+            out["extra"] = {"cfg5_fmc": fm, "tfm_columns": tc}
+    if world == 1 and rank == 0 and not args.no_extra and "extra" in out:
+        out["extra"]["tfm_columns"] = tfm_columns(dev_api, dist_api, t64, torch, dev, 0, 1, barrier, max_over_ranks, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def tfm_columns(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args):
+    """The pipeline that needs every element per focal point — travel-time table -> TFM delay-and-sum — sharded by COLUMNS (focal
+    points), strong-scaled: rank r solves tt[all 64 elements, its slice of a 1024 x 1024 image], beamforms the slice, and the image
+    slices (4 B per focal point) are all-gathered INSIDE the timed region every step (dist.tfm_layers_sharded).  No travel time
+    crosses a link: this is the multi-GPU shape of the path whose collective is small enough to scale with."""
+    import rtus  # noqa: F401
+    g = 256 if SMALL else 1024
+    n_el, n_t, fs = 64, 2048, 50e6
+    z_if, c = [0.010, 0.025], [2330.0, 1483.0, 5900.0]
+    xe = t64((np.arange(n_el) - (n_el - 1) / 2.0) * 0.6e-3)
+    ze = t64(np.zeros(n_el))
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, g), np.linspace(0.026, 0.066, g))
+    xf, zf = t64(xs.ravel()), t64(zs.ravel())
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    fmc = torch.randn((n_el, n_el, n_t), dtype=torch.float32, device=dev, generator=gen)
+    res = {"workload": f"{n_el}-element FMC record ({n_el} x {n_el} x {n_t} samples, synthetic noise) -> {g} x {g} TFM image through 2 planar "
+                       f"interfaces: travel-time table + delay-and-sum per focal-point slice, image slices all-gathered every step",
+           "focal_points_per_gpu": -(-g * g // world)}
+    try:
+        step = lambda s=None: dist_api.tfm_layers_sharded(fmc, fs, z_if, c, xe, ze, xf, zf, t0=0.0)
+        for _ in range(3):
+            img = step()
+        torch.cuda.synchronize()
+        K = 10
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            img = step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        pairs = float(n_el) * n_el * g * g
+        res.update({"ms_per_image": round(dt / K * 1e3, 4), "steps": K, "G_pair_samples_per_s": round(pairs * K / dt / 1e9, 1),
+                    "Mrays_per_s_table_part": round(n_el * g * g * K / dt / 1e6, 1),
+                    "collective": "all_gather_into_tensor of the image slices inside the timed region" if world > 1 else "none (one GPU)",
+                    "collective_bytes_received_per_rank": 4 * (g * g - g * g // world) if world > 1 else 0,
+                    "image_checksum": float(img.double().abs().sum())})
+    except Exception as exc:
+        res["error"] = repr(exc)
+    return res
 
 
 def fmc_strong(dev_api, dist_api, t64, torch, dev, rank, world, barrier, max_over_ranks, args):
@@ -842,6 +899,8 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
         n = rows * Wl["n_f"]
         res[name] = {"Mrays_per_s": round(n / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "solves_per_launch": n,
                      "hbm_frac": round(n * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if rows == 1024:
+            res.setdefault("_lens_samples", {})[name] = _table_sample(torch, outl, txe, tze, txf, tzf, seed=4)
         del outl
     # fp64 instantiation of the same kernel on a 1024 x (1024 x 256) strip
     Wl = lens_inputs(0, 1)
@@ -856,6 +915,7 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
     ms = _event_ms(torch, run, 5)
     res["lens_fermat_f64"] = {"Mrays_per_s": round(1024 * nf64 / ms / 1e3, 1), "ms_per_launch": round(ms, 4),
                               "solves_per_launch": 1024 * nf64}
+    res.setdefault("_lens_samples", {})["lens_fermat_f64"] = _table_sample(torch, outl, txe, tze, txf, tzf, seed=5)
     del outl
     # --- BASELINE configs[4]: the whole 2048 x 2048 FMC table on one GPU --------------------------------------------
     Wf = fmc_inputs(0, 1)
@@ -885,9 +945,48 @@ def extra_measurements(dev_api, dist_api, rtus, t64, torch, dev):
     tt = sol[0]
     res["solve_sweep_host_api"] = {"ms_per_pass": round(dtm * 1e3, 3), "elements": int(tt.size), "M_element_solves_per_s": round(tt.size / dtm / 1e6, 1),
                                    "with_root": int(np.isfinite(tt).sum()), "note": "host-buffer API incl. PCIe"}
+    # --- the NumPy-in / NumPy-out table call (PCIe inclusive; never `value`): configs[1] and configs[2], one device and two arenas ----
+    for nm, wl_ in (("cfg2", "cfg2_planar"), ("cfg3", "cfg3_planar")):
+        Wh = planar_inputs(wl_, 0, 1)
+        outh = np.empty((Wh["n_e"], Wh["n_f"]))
+        for label, kw in (("one_device", {}), ("devices_0_0", {"devices": [0, 0]}), ("one_device_taup", {"taup": True})):
+            call = lambda: rtus.travel_time_layers(Wh["z_if"], Wh["c"], Wh["xe"], Wh["ze"], Wh["xf"], Wh["zf"], out=outh, **kw)
+            ms_h = _best_ms(torch, call, 3, blocks=3)
+            res.setdefault("host_api_tables", {})[f"{nm}_{label}"] = {
+                "ms_per_call": round(ms_h, 3), "GB_per_s_of_results": round(outh.nbytes / (ms_h * 1e-3) / 1e9, 2),
+                "Mrays_per_s": round(outh.size / ms_h / 1e3, 1)}
+    res["host_api_tables"]["note"] = ("rtus.travel_time_layers: host buffers in, host table out — bound by the device-to-host copy of the table "
+                                      "(pageable memory), not by the kernel; devices=[0, 0]: two arenas / streams / copy threads on the one GPU")
     # --- the reference's calling pattern: 210 sequential shoot_rays(N = 905) calls + matcher (main_rt.py:464-504) ------
     res["sweep_like_main_rt"] = sweep_like_reference(rtus)
     return res
+
+
+def _table_sample(torch, table, txe, tze, txf, tzf, seed, n_rows=8, n_cols=2048):
+    """a seeded sample of a device table with the coordinates the kernel saw (as float64) -> host arrays for the accuracy leg"""
+    rng = np.random.default_rng(seed)
+    re = np.sort(rng.choice(table.shape[0], size=n_rows, replace=False))
+    cf = np.sort(rng.choice(table.shape[1], size=n_cols, replace=False))
+    ri, ci = torch.as_tensor(re, device=table.device), torch.as_tensor(cf, device=table.device)
+    f = lambda t, i: t[i].double().cpu().numpy()
+    return dict(xe=f(txe, ri), ze=f(tze, ri), xf=f(txf, ci), zf=f(tzf, ci), got=table[ri][:, ci].double().cpu().numpy(),
+                dtype=str(table.dtype).replace("torch.", ""))
+
+
+def lens_tables_accuracy(samples):
+    """(part of the CPU leg: the only place besides cpu_baseline / cpu_ref_path where bench.py touches oracle/) the curved-lens
+    tables timed in `extra` — the whole fp32 table of configs[3] and the fp64 table — against orc_tt_lens on a seeded sample"""
+    import rtus
+    from oracle import cport
+    out = {}
+    for name, smp in samples.items():
+        ref, _ = cport.tt_lens(smp["xe"], smp["ze"], smp["xf"], smp["zf"], -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
+        d = np.abs(smp["got"] - ref)
+        out[name] = {"max_abs_dt_s": float(np.nanmax(d)), "median_abs_dt_s": float(np.nanmedian(d)), "dtype": smp["dtype"],
+                     "nan_masks_identical": bool(np.array_equal(np.isnan(smp["got"]), np.isnan(ref))),
+                     "sample": f"{smp['got'].shape[0]} seeded-random rows x {smp['got'].shape[1]} seeded-random targets of the timed table",
+                     "checker": "orc_tt_lens (scan + golden section, long double)", "bar_s": 1e-9}
+    return out
 
 
 def solve_inputs(kind):

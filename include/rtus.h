@@ -100,10 +100,32 @@ int rtus_selftest(const rtus_lens *lens, int n_rays, long long n_math, unsigned 
  *   status  [n_geom][n_tx][n_rays]      nullable  RTUS_RAY_* bits
  * ---------------------------------------------------------------------------------------- */
 /* flags for rtus_shoot*:
- *   0                     reference-compatible arithmetic: the reference's angle form (atan2 / asin / tan),
- *                         operation for operation, no FMA contraction — reproduces even its rounding-decided rays.
- *   RTUS_SHOOT_FAST_MATH  the same laws in vector form (no trigonometry): ~1e-15 relative from the above on
- *                         regular rays, may differ on degenerate ones (exactly vertical / tangent rays). */
+ *   0                     REFERENCE-COMPATIBLE.  What that means since round 3 (it is no longer the reference's angle chain
+ *                         operation for operation):
+ *                         - the reference's laws, quirks and decisions: chord polyline of the alpha grid (main_rt.py:385-390), pipe
+ *                           tangent without the offset (:237-238, 367), lens root [1] / upper circle root (:187, 362-364), first sign
+ *                           change in index order with np.sign(0) = 0 (:82-99), the +-1e-9 bounds check (:153-168), NaN for
+ *                           total reflection and for |x_q| > r, no FMA contraction;
+ *                         - formed AS THE REFERENCE FORMS THEM: the lens point and tangent (:180-234), the refracted angle
+ *                           phi_pq = phi_s - pi/2 + asin(eta sin theta_1) and a = tan(phi_pq) (:267-280, 348: with the library's own
+ *                           atan2 / sin / asin / tan where |a| > 300 — there the quadratic of :349-364 amplifies a last bit by |a|^3),
+ *                           the circle intersection in slope-intercept form (:349-364), the chord intersection (:127-150), the landing
+ *                           point (:402-404), the four segment times (:497-500), all with correctly rounded division / square root;
+ *                         - formed ALGEBRAICALLY (the same real-number value, a few ulp from the reference's chain): sin theta_1 of the
+ *                           entry refraction as a dot product of unit vectors; the reflected slope tan(2 atan(s) - phi_pq) as a rational
+ *                           form in s's numerator and denominator (:283-292, 375); the exit refraction tan(phi_s - pi/2 + asin(eta
+ *                           sin(...))) in vector form (:396-401) — total reflection is decided on eta sin theta_1 > 1 as in the reference,
+ *                           but on a value ~1 ulp from its own, so a ray within a few ulp of the critical angle may be NaN on one side
+ *                           and finite on the other (parity unpinned AT the critical angle; no golden ray sits there).
+ *                         Guarantee, tested: NaN masks identical and every output within 1e-12 m / 1e-15 s on every golden captured from
+ *                         the reference (tests/golden, the .npz files, 30 calls), database_2.csv's 13,650 flags and compare.csv's 1,810 rows
+ *                         reproduced, and on random inputs |gpu - oracle| <= 1e-12 m + 16 x the oracle's OWN spread under 1-2 ulp
+ *                         noise of its trigonometry (scripts/fuzz_shoot.py).  Measured on ill-conditioned rays (near-vertical lines,
+ *                         grazing chords — the oracle moves as much under that noise): up to 8e-6 m from the oracle; and
+ *                         tests/test_gpu_sweep_random_rows.py: the matcher's hit / first-ray decisions on 2,100 random rows outside
+ *                         database_2.csv agree wherever the oracle keeps its own decision under that noise.
+ *   RTUS_SHOOT_FAST_MATH  the same laws in vector form throughout (no trigonometry, reciprocal / rsqrt seeds + Newton): ~1e-15
+ *                         relative from the above on regular rays, may differ on degenerate ones (exactly vertical / tangent rays). */
 #define RTUS_SHOOT_FAST_MATH 0x1u
 /* Physically-correct variants — these DEPART from the reference on purpose:
  *   RTUS_TRUE_PIPE_TANGENT  reflect on the tangent of the circle where it actually is; the reference evaluates

@@ -291,8 +291,11 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
             const double xn = __shfl_down(xv, 1);
             const bool asc = !__ballot(ev && lane < 63 && c0 + lane + 1 < a.n_rx && !(xv <= xn));
             // ascending chunk: x + tol and x - tol ascend with x (rtol < 1), so the elements a landing point of this wave can
-            // match are [#{x + tol < lo}, #{x - tol <= hi})
-            const int nlo = __popcll(__ballot(ev && xv + tolv < wlo)), nhi = __popcll(__ballot(ev && xv - tolv <= whi));
+            // match are [#{x + tol < lo}, #{x - tol <= hi}) — with the tolerance widened by a few ulp of the operands, so that the
+            // rounding of x + tol here can never drop an element whose rounded |x_land - x| is exactly tol; the test
+            // itself, below, is np.isclose's
+            const double tolw = tolv + 8.0 * 2.220446049250313e-16 * (fabs(xv) + fabs(tolv));
+            const int nlo = __popcll(__ballot(ev && xv + tolw < wlo)), nhi = __popcll(__ballot(ev && xv - tolw <= whi));
             const bool mono = asc && a.rtol < 1.0;
             const int e0 = mono ? nlo : 0, e1 = mono ? nhi : min(64, a.n_rx - c0);
             int cand = RTUS_NO_RAY;

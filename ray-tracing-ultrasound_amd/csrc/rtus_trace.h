@@ -242,10 +242,13 @@ __device__ __forceinline__ double cap_vertical(double ux, double uz)
 struct RayIn { double2 P; double phis; double2 tu; double xa, za, r_outer, off, zf; };   // phis: compat; tu: both modes
 struct RayOut { double xq, zq, xi, zi, x_in; };
 
-// Reference-compatible mode (FAST = false): the reference's angle arithmetic, operation for operation, with sin / tan /
-// atan2 / atan / asin through the kernels of rtus_trig.h, correctly rounded division and square root (rtus_div,
-// rtus_sqrt) and the lens at alpha_i = atan2(x_i, z_i) through x_i / rho, z_i / rho (no angle formed): 1,200 instead
-// of 2,066 executed VALU instructions per wave.  ONE place keeps the library's routines: the first refraction of a wave
+// Reference-compatible mode (FAST = false).  Round 1 - 2: the reference's angle arithmetic, operation for operation (sin / tan /
+// atan2 / atan / asin through the kernels of rtus_trig.h).  Since round 3 only phi_pq = phi_s - pi/2 + asin(eta sin theta_1) and
+// a = tan(phi_pq) are still formed as angles; sin theta_1, the reflection and the exit refraction are algebraic restatements (a few
+// ulp from the reference's chain; include/rtus.h "flags for rtus_shoot*" says what that guarantees and what it does not — e.g. a ray
+// within a few ulp of the critical angle at the exit may be NaN here and finite there).  Division and square root are correctly
+// rounded (rtus_div, rtus_sqrt); the lens at alpha_i = atan2(x_i, z_i) goes through x_i / rho, z_i / rho (no angle formed).
+// ONE place keeps the library's routines: the first refraction of a wave
 // that holds a near-vertical refracted line (|a_pq| > 300: ~1 % of the waves).  The
 // reference intersects that line with the pipe through the quadratic formula in slope-intercept form
 // (main_rt.py:349-364), which amplifies a last-bit difference of the angle by ~|a_pq|^3 — bit-level agreement with its

@@ -102,7 +102,10 @@ def travel_time_layers_sharded(z_if, c, xe, ze, xf, zf, *, group=None, solver=No
         align = rows_per_block(n_rows, xf.numel()) if align is None else align
 
     def rows(lo, hi, out):
-        solver(z_if, c, xe[lo:hi].contiguous(), ze[lo:hi].contiguous(), xf, zf, out=out, row0=lo, n_rows_total=n_rows)
+        xs, zs = xe[lo:hi].contiguous(), ze[lo:hi].contiguous()
+        solver(z_if, c, xs, zs, xf, zf, out=out, row0=lo, n_rows_total=n_rows)
+        if xs.is_cuda:
+            torch.cuda.current_stream(xs.device).synchronize()     # xs / zs (possibly temporaries) must outlive the asynchronous launch
     return sharded_rows(n_rows, xf.numel(), rows, dtype=xe.dtype, device=xe.device, group=group, align=1 if align is None else align)
 
 

@@ -117,6 +117,7 @@ def main():
     trials = int(args[0]) if len(args) > 0 else 150
     rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 12345)
     worst_ratio, worst_abs, rays, decided, noted, hard_total, t0 = 0.0, 0.0, 0, 0, 0, 0, time.time()
+    second_looks, second_passes = 0, 0                         # traces that failed the first rule / of those, that passed the second look
     for trial in range(trials):
         n = int(rng.choice([rng.integers(2, 20), rng.integers(20, 600), rng.integers(600, 4200), rng.integers(4200, 9000)]))
         if rng.random() < 0.5:
@@ -152,11 +153,15 @@ def main():
                     # rays thinly.  Second look with 48 more noise patterns, same rule: disagreements only on rays the reference's
                     # own arithmetic decides by rounding, plus a quarter of their number.
                     more = nan_stable_under(MORE_NOISE_MODES, xa[t:t + 1], za[t:t + 1], zf, alpha, geoms[gi:gi + 1])[0, 0]
+                    second_looks += 1
+                    first_rule = (int(hard.sum()), n_unstable)
                     ray_stable = ray_stable & more
                     n_unstable = int((~ray_stable).sum())
                     hard = mism & ray_stable
                     print(f"note: degenerate trace, second look (62 noise patterns): trial {trial} geom={geoms[gi]} xa={xa[t]}: "
-                          f"{n_unstable} ray(s) flip in the oracle, {int(hard.sum())} disagreement(s) elsewhere")
+                          f"{n_unstable} ray(s) flip in the oracle, {int(hard.sum())} disagreement(s) elsewhere "
+                          f"(first rule, 14 patterns: {first_rule[0]} disagreement(s) against {first_rule[1]} flipping ray(s))")
+                    second_passes += int(hard.sum() <= n_unstable // 4)
                 if hard.sum() > n_unstable // 4:
                     bad = np.flatnonzero(hard)
                     print(f"NaN MASK MISMATCH trial {trial} n={n} geom={geoms[gi]} xa={xa[t]}: {hard.sum()} ray(s), first {bad[:5].tolist()}, "
@@ -199,7 +204,8 @@ def main():
         sys.exit(1)
     print(f"OK: {trials} trials, {rays} rays, worst |d| {worst_abs:.2e} m, worst |d| / (1e-12 + 16 spread) {worst_ratio:.3f}; "
           f"{noted} case(s) above 1e-12 m inside their own spread; {decided} rounding-decided ray(s) (NaN status moves with 1-2 ulp of "
-          f"the inputs in the oracle itself, or next to such rays: {hard_total})")
+          f"the inputs in the oracle itself, or next to such rays: {hard_total}); "
+          f"SECOND LOOKS: {second_looks} trace(s) of {trials * 9} failed the first rule (14 noise patterns), {second_passes} of them passed with 62")
 
 
 if __name__ == "__main__":

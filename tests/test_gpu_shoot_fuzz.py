@@ -18,6 +18,12 @@ def test_fuzz_forward_trace_vs_oracle(rtus):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK: 40 trials" in r.stdout
+    # the first rule (fourteen noise patterns) is the gate: a trace that needs the second look is counted, not waved through
+    import re
+    m = re.search(r"SECOND LOOKS: (\d+) trace\(s\) of (\d+) failed the first rule .*?, (\d+) of them passed", r.stdout)
+    assert m, r.stdout[-500:]
+    print(r.stdout.strip().splitlines()[-1])
+    assert int(m.group(1)) == 0, f"{m.group(1)} of {m.group(2)} traces failed the first rule (second look passed {m.group(3)})"
 
 
 def test_fuzz_criterion_catches_a_wrong_segment(rtus):

@@ -1,0 +1,83 @@
+"""GPU: the `hitted` / first-ray decisions of the reference's matcher (main_rt.py:487-501) on rows the reference's own sweep never ran.
+
+database_2.csv pins the flags of 210 geometries x one transmit point; the reference-compatible trace is no longer the reference's
+angle arithmetic operation for operation (include/rtus.h, "flags for rtus_shoot*"), and a landing point a few 1e-7 m off can flip a
+flag at atol = 1e-6 m.  Here: 2,100 seeded random (geometry, transmit point) rows x 905 rays x the 65 elements
+through the fused sweep (rtus_sweep: trace + matcher in one kernel) against the oracle's trace + scan.  Every disagreement is listed
+with the landing miss that caused it and classified: does the ORACLE ITSELF keep that decision when each of its trigonometric results
+moves by 0 / +-1 / +2 ulp (fourteen patterns — what another math library does to the reference, which is how the GPU differs from it)?
+Done = no disagreement on a decision the oracle keeps; the others are counted and printed.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import D_PLANE
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_decisions(cport, xa, za, zf, alpha, geoms, xe, atol):
+    o8 = cport.shoot_batch(xa, za, zf, alpha, geoms)                       # [G, T, 8, n]
+    G, T = o8.shape[:2]
+    hit = np.zeros((G, T, xe.size), dtype=bool)
+    first = np.zeros((G, T, xe.size), dtype=np.int32)
+    for g in range(G):
+        for t in range(T):
+            h, _, f = cport.match(o8[g, t, 6], cport.tof4(xa[t], za[t], o8[g, t]), xe, atol)
+            hit[g, t], first[g, t] = h, np.where(h, f, -1)
+    return o8[:, :, 6], hit, first
+
+
+def test_hit_flags_on_2100_random_rows(rtus):
+    from oracle import cport
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from fuzz_shoot import NOISE_MODES
+    rng = np.random.default_rng(20264)
+    n, G, T, atol = 905, 105, 20, 1e-6
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)                # the reference's grid (main_rt.py:479)
+    zf = np.full(n, D_PLANE)
+    geoms = np.stack([rng.uniform(0.008, 0.11, G), rng.uniform(-0.012, 0.012, G)], axis=1)      # not the 210 of the reference's sweep
+    geoms[:5, 1] = 0.0                                                     # centred pipes: every ray retraces itself when tx = 0
+    xa = np.concatenate([[0.0], rng.uniform(-0.019, 0.019, T - 1)])
+    za = np.full(T, D_PLANE)
+    xe = rtus.reference_elements()
+    got = rtus.sweep_batch(xa, za, zf, alpha, xe, geoms=geoms, params=rtus.Params(), atol=atol, want=("land_x",))
+    g_hit, g_first = got["hit"], np.where(got["hit"], got["first_ray"], -1)
+    land, o_hit, o_first = _oracle_decisions(cport, xa, za, zf, alpha, geoms, xe, atol)
+    assert o_hit.shape == g_hit.shape == (G, T, 65) and G * T >= 2000
+    diff = np.argwhere((g_hit != o_hit) | (g_first != o_first))
+    # which decisions does the oracle itself keep under last-bit noise of its trigonometry?
+    kept_hit = np.ones_like(o_hit)
+    kept_first = np.ones_like(o_hit)
+    if len(diff):
+        rows = sorted({(int(g), int(t)) for g, t, _ in diff})
+        try:
+            for mode in NOISE_MODES + [int(v) for v in np.random.default_rng(5).integers(1, 2 ** 32, 4)]:
+                cport.set_trig_noise(mode)
+                for g, t in rows:
+                    _, h, f = _oracle_decisions(cport, xa[t:t + 1], za[t:t + 1], zf, alpha, geoms[g:g + 1], xe, atol)
+                    kept_hit[g, t] &= h[0, 0] == o_hit[g, t]
+                    kept_first[g, t] &= f[0, 0] == o_first[g, t]
+        finally:
+            cport.set_trig_noise(0)
+    hard = []
+    tol = atol + 1e-5 * np.abs(xe)
+    for g, t, e in diff:
+        ray = int(max(g_first[g, t, e], o_first[g, t, e]))                 # the ray one side matched and the other did not / matched later
+        rays = sorted({int(r) for r in (g_first[g, t, e], o_first[g, t, e]) if r >= 0})
+        miss = [(r, float(abs(land[g, t, r] - xe[e]) - tol[e]), float(abs(got["land_x"][g, t, r] - xe[e]) - tol[e])) for r in rays]
+        kept = bool(kept_hit[g, t, e] and kept_first[g, t, e])
+        print(f"geom {geoms[g].tolist()} tx {xa[t]:+.6f} elem {e}: gpu hit {bool(g_hit[g, t, e])} first {g_first[g, t, e]} | oracle hit "
+              f"{bool(o_hit[g, t, e])} first {o_first[g, t, e]} | (ray, oracle |x_land - x_e| - tol, gpu ...) {miss} | the oracle "
+              f"{'KEEPS' if kept else 'does not keep'} its decision under 1-2 ulp of its trigonometry")
+        if kept:
+            hard.append((g, t, e, ray))
+    n_hits = int(o_hit.sum())
+    print(f"{G * T} rows x 65 elements: {n_hits} oracle hits, {len(diff)} (row, element) decisions differ, {len(hard)} of them on decisions the "
+          f"oracle keeps under last-bit perturbations of its own trigonometry")
+    assert n_hits > 1500                                                   # the comparison is about something
+    assert not hard, hard[:10]
