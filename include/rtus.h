@@ -180,6 +180,13 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
  * (the hit ray lands up to atol + rtol|x| away from the element: <= ~3e-9 s, more at turning points of x_land).
  * ---------------------------------------------------------------------------------------- */
 #define RTUS_MAX_ROOTS 4
+/* How a bracket is refined depends on the SIZE of the call (a function of n_geom * n_tx * n_rx, nothing else): up to 32,768 (row,
+ * element) pairs — the reference's own sweep has 13,650 — three lanes per bracket (the candidate and its two neighbours together:
+ * two rounds of evaluations instead of two or three; such a call leaves most of the chip idle and lasts as long as its slowest
+ * bracket), beyond that one lane per bracket.  Both schemes answer to the same tolerances (|dt| <= 1e-13 s, |dalpha| <= 1e-11 rad
+ * against bisection); within one scheme a bracket's bits do not depend on the aperture's order or on the other brackets of the
+ * call.  RTUS_SOLVE_ONE_LANE asks for the one-lane scheme whatever the size (bits independent of the call's size too). */
+#define RTUS_SOLVE_ONE_LANE 0x10u
 
 size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx);
 

@@ -358,14 +358,19 @@ def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0,
                               np.full(x_rx.size, 2.0 * z_reflector - float(z_array)), device=device, devices=devices, taup=taup)
 
 
+SOLVE_ONE_LANE = 0x10       # RTUS_SOLVE_ONE_LANE (include/rtus.h)
+
+
 def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params: Params = None, fast=False,
-                       true_tangent=False, analytic_lens=False, all_roots=False, device=0):
+                       true_tangent=False, analytic_lens=False, all_roots=False, one_lane=False, device=0):
     """Pulse-echo travel times tx -> lens -> pipe -> lens -> rx by root-finding x_land(alpha) = x_rx — the
     replacement for the reference's grid scan + tolerance matcher (main_rt.py:479-501).
 
     Returns tt [G, T, E] (least time over the element's ray paths, NaN if none) and the launch angle
     alpha_root [G, T, E]; with all_roots also (tt_all, alpha_all) [G, T, E, 4] in ascending alpha and
     n_roots [G, T, E].  ``true_tangent`` / ``analytic_lens`` switch on the physically-correct variants.
+    ``one_lane``: refine every bracket by one lane whatever the size of the call (RTUS_SOLVE_ONE_LANE; calls of up to 32,768
+    (row, element) pairs otherwise use three lanes per bracket — same tolerances, other last bits).
     """
     p = _resolve(params)
     x_a, z_a = _f64(x_a, "x_a"), _f64(z_a, "z_a")
@@ -387,7 +392,7 @@ def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params
     lens = p.lens()
     st = _lib.lib().rtus_solve(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), alpha.size,
                                _ptr(x_rx), E, z_land, _ptr(tt), _ptr(ar), _ptr(ta), _ptr(aa), _ptr(nr),
-                               _flags(fast, true_tangent, analytic_lens), int(device))
+                               _flags(fast, true_tangent, analytic_lens) | (SOLVE_ONE_LANE if one_lane else 0), int(device))
     _lib.check(st, "rtus_solve")
     return (tt, ar, ta, aa, nr) if all_roots else (tt, ar)
 

@@ -96,9 +96,22 @@ __device__ __forceinline__ double solve_iqi(double xa, double fa, double xb, dou
 // about one bracket per element the list then fits ONE trip of the four waves even where elements have two (a list of 260
 // brackets on 256 lanes costs its workgroup a second trip for four of them — in a launch of a few hundred waves that trip is
 // the kernel's critical path).  The launcher takes 128 for launches that leave SIMDs idle anyway.
-template <bool FAST, bool MASKS, int EPB = RTUS_SOLVE_TPB>
+// TRIO (round 4; small launches only — the launcher's choice is a function of the call's size, so which scheme refines a bracket is
+// too): THREE LANES PER BRACKET.  In a launch that leaves most SIMDs idle the kernel lasts as long as its slowest wave's chain of
+// dependent evaluations (~11 us each), and with one lane per bracket 0.7 % of the brackets — a third of the waves — need a third one.
+// Here every round evaluates cand - d, cand, cand + d on three lanes of one wave and the bracket's root is the zero of the inverse
+// quadratic through the three fresh points, T the parabola through their times.  x_land(alpha) has KINKS — where the returning ray
+// moves to the next chord of the lens polyline its slope jumps by ~1e-4 relative — so a wide triple that straddles one is off by
+// d x that jump: the zero is ACCEPTED only from a triple with d <= 1e-8 rad (error <= 1e-12 rad, third order without a kink); the
+// first round (d = 3e-6 ... 1e-4, from how far the quadratic term moved the candidate off the secant's zero) only supplies the
+// second round's centre, good to ~3e-10.  scripts/proto_solve_3lane.c on the sweep's 40,459 brackets: two rounds for 99.95 % (one
+// lane per bracket: 99.3 %, and the rest cost their waves a third evaluation), the same root / no-root decisions as bisection,
+// |dT| <= 7e-17 s, |dalpha| <= 1.1e-11 rad.  21 brackets per wave.
+#define RTUS_TRIO_PER_WAVE 21
+template <bool FAST, bool MASKS, int EPB = RTUS_SOLVE_TPB, bool TRIO = false>
 __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(RTUS_SOLVE_MIN_WAVES, 8))) void rtus_solve_kernel(SolveArgs q)
 {
+    __shared__ double tri[TRIO ? RTUS_SOLVE_WAVES : 1][TRIO ? 64 : 1][2];   // TRIO: per lane, landing residual and time of its latest evaluation
     __shared__ unsigned items[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];        // (slot << 2 | k) is implied by position: see below
     __shared__ int item_r[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
     __shared__ double res_t[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS], res_a[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
@@ -235,6 +248,120 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
 
     STAMP(2);
     // ---- C: lanes = brackets ---------------------------------------------------------------------------------------------
+    if constexpr (TRIO) {
+    for (int i0 = wv * RTUS_TRIO_PER_WAVE; i0 < total; i0 += RTUS_SOLVE_WAVES * RTUS_TRIO_PER_WAVE) {   // wave-uniform
+        const int jb = min(lane / 3, RTUS_TRIO_PER_WAVE - 1), role = lane - 3 * (lane / 3);   // role 0 / 1 / 2 = cand - d / cand / cand + d (lane 63 idles along)
+        const bool mine = i0 + jb < total && lane < 3 * RTUS_TRIO_PER_WAVE && role == 1;
+        const int ii = min(i0 + jb, total - 1);
+        const unsigned slot = items[ii];
+        const int br = item_r[ii];
+        const int owner = (int)(slot >> 2);
+        long long row;
+        int ie;
+        if (MASKS) {
+            const long long fl = (long long)blockIdx.x * EPB + owner;
+            row = fl / q.n_rx;
+            ie = (int)(fl - row * q.n_rx);
+        } else {
+            const long long itask = (long long)blockIdx.x * RTUS_SOLVE_WAVES + (owner >> 6);
+            row = itask / q.chunks;
+            ie = (int)(itask - row * q.chunks) * 64 + (owner & 63);
+        }
+        const int g = (int)(row / a.n_tx), tx = (int)(row - (long long)g * a.n_tx);
+        const double xr = q.x_rx[ie];
+        const double* __restrict__ lrow = q.land_x + (size_t)row * n;
+        RayIn in;
+        in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];
+        in.xa = a.x_a[tx]; in.za = a.z_a[tx]; in.zf = q.z_land;
+        double xlo = q.alpha[br], xhi = q.alpha[br + 1];
+        double flo = lrow[br] - xr, fhi = lrow[br + 1] - xr;
+        double xt, ft;                                                   // third grid ray: as in the one-lane scheme below
+        {
+            const bool left = fabs(flo) < fabs(fhi);
+            const int t1 = left ? br - 1 : br + 2, t2 = left ? br + 2 : br - 1;
+            const int c1 = min(max(t1, 0), n - 1), c2 = min(max(t2, 0), n - 1);
+            const double l1 = lrow[c1], l2 = lrow[c2];
+            const bool ok1 = c1 == t1 && isfinite(l1), ok2 = c2 == t2 && isfinite(l2);
+            xt = q.alpha[ok1 ? c1 : c2];
+            ft = (ok1 ? l1 : (ok2 ? l2 : NAN)) - xr;
+        }
+        const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
+        const double sec = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
+        double cand = solve_iqi(xlo, flo, xhi, fhi, xt, ft);             // NaN without a third ray
+        if (!(cand > xlo && cand < xhi)) cand = sec;
+        if (!(cand > xlo && cand < xhi)) cand = 0.5 * (xlo + xhi);
+        // how far the candidate may be off: a fraction of what the quadratic term moved it from the secant's zero
+        double delta = fmin(fmax(0.08 * fabs(cand - sec), 3e-6), 1e-4);
+        if (single) { cand = (fhi == 0.0 || fabs(fhi) < fabs(flo)) ? xhi : xlo; delta = 0.0; }
+        double fprev_abs = INFINITY;
+        double x_fin = NAN, T_fin = NAN, f_fin = NAN;
+        bool done = false, dead = false;
+        for (int it = 0; it < 48; ++it) {
+            if (!__any(!done)) break;
+            STAMP(3 + min(it, 9));
+            if (!single) delta = fmin(delta, 0.999 * fmin(cand - xlo, xhi - cand));
+            const double ac = cand + (double)(role - 1) * delta;
+            double sn, cs, px, pz, dz, dx;
+            rtus_sincos(ac, sn, cs);
+            lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
+            in.P = make_double2(px, pz);
+            { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+            if (!FAST) in.phis = rtus_atan2(dz, dx);
+            RayOut o;
+            trace_ray<FAST>(a, in, o);                                   // all 64 lanes together
+            const double t1 = seg_time<FAST>(in.xa, in.za, px, pz, k.c1, k.inv_c1);
+            const double t2 = seg_time<FAST>(px, pz, o.xq, o.zq, k.c2, k.inv_c2);
+            const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
+            const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
+            tri[wv][lane][0] = o.x_in - xr;
+            tri[wv][lane][1] = ((t1 + t2) + t3) + t4;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double fm = tri[wv][3 * jb][0], f0 = tri[wv][3 * jb + 1][0], fq = tri[wv][3 * jb + 2][0];
+            const double Tm = tri[wv][3 * jb][1], T0 = tri[wv][3 * jb + 1][1], Tq = tri[wv][3 * jb + 2][1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!done) {                                                 // (the three lanes of a bracket decide alike: same inputs)
+                if (!isfinite(f0)) { dead = true; done = true; }         // the branch ends inside the bracket
+                else if (single || f0 == 0.0) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }
+                else {
+                    const bool mono = isfinite(fm) && isfinite(fq) && (fq - f0) * (f0 - fm) > 0.0 && delta > 0.0;
+                    double x3 = NAN;
+                    if (mono) {
+                        x3 = solve_iqi(cand, f0, cand - delta, fm, cand + delta, fq);
+                        const double u = (x3 - cand) * solve_rcp(delta);
+                        if (delta <= 1e-8 && fabs(u) <= 8.0) {       // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad)
+                            done = true;
+                            f_fin = 0.0;                                 // a root next to three fresh points
+                            x_fin = x3;
+                            T_fin = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm)));
+                        }
+                    }
+                    if (!done) {
+                        // the three points tighten the bracket; the next centre comes from them
+                        const double xs0 = cand - delta, xs2 = cand + delta;
+                        if (isfinite(fm)) { if ((fm < 0.0) == (flo < 0.0)) { if (xs0 > xlo) { xlo = xs0; flo = fm; } } else if (xs0 < xhi) { xhi = xs0; fhi = fm; } }
+                        { if ((f0 < 0.0) == (flo < 0.0)) { if (cand > xlo) { xlo = cand; flo = f0; } } else if (cand < xhi) { xhi = cand; fhi = f0; } }
+                        if (isfinite(fq)) { if ((fq < 0.0) == (flo < 0.0)) { if (xs2 > xlo) { xlo = xs2; flo = fq; } } else if (xs2 < xhi) { xhi = xs2; fhi = fq; } }
+                        if (xhi - xlo <= 1e-13) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }      // a jump — or the root itself
+                        else {
+                            double nc = x3;
+                            if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
+                            if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev_abs) { nc = 0.5 * (xlo + xhi); delta = 0.25 * (xhi - xlo); }
+                            else delta = fmax(fmin(fmax(3e-9, fmin(1e-4 * delta, 1e-8)), 0.25 * fabs(nc - cand)), 1e-11);   // (a wide first triple may straddle a kink: its zero is good to ~1e-4 d)
+                            fprev_abs = fabs(f0);
+                            x_fin = cand; T_fin = T0; f_fin = f0;        // (what an exhausted iteration reports)
+                            cand = nc;
+                        }
+                    }
+                }
+            }
+        }
+        const bool root = done && !dead && fabs(f_fin) < 1e-9;           // |f| large at convergence: a jump, not a root
+        if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
+    }
+    } else {
     for (int i0 = wv * 64; i0 < total; i0 += RTUS_SOLVE_TPB) {          // wave-uniform
         const bool mine = i0 + lane < total;
         const int ii = min(i0 + lane, total - 1);                       // idle lanes redo the last bracket (no store)
@@ -400,6 +527,7 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         const bool root = !dead && fabs(f_fin) < 1e-9;                   // |f| large at convergence: a jump, not a root
         if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
     }
+    }
     STAMP(13);
     __syncthreads();
     STAMP(14);
@@ -474,13 +602,24 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
     // mask mode, launches that leave SIMDs idle anyway (fewer than two waves of elements per SIMD): 128 element lanes per workgroup
     const bool half = masks && q.n_tasks <= 2LL * 1024 * 64;
-    const long long epb = half ? RTUS_SOLVE_TPB / 2 : RTUS_SOLVE_TPB;
+    // ... and three lanes per bracket where even that leaves the chip mostly idle (<= 32,768 elements: ~1.5 waves per SIMD with
+    // three lanes per bracket): 32 element lanes per workgroup, so that its brackets x 3 lanes fit ONE trip of its four waves (84
+    // brackets) even where most elements have two or three — a workgroup that needs a second trip doubles the kernel's critical
+    // path (measured with 64 element lanes: the first evaluation of the slowest waves started 31 us into a 43 us kernel)
+    const bool trio = (long long)n_geom * n_tx * n_rx <= 32768 && !(flags & RTUS_SOLVE_ONE_LANE);   // (either bracket-finding path)
+    const long long epb = (trio && masks) ? RTUS_SOLVE_TPB / 8 : (half ? RTUS_SOLVE_TPB / 2 : RTUS_SOLVE_TPB);
     const long long blocks = masks ? (q.n_tasks + epb - 1) / epb : (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks);
     const bool fast = (flags & RTUS_SHOOT_FAST_MATH) != 0;
 #define RTUS_SOLVE_LAUNCH(F, M, E) hipLaunchKernelGGL((rtus_solve_kernel<F, M, E>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q)
-    if (half) { if (fast) RTUS_SOLVE_LAUNCH(true, true, RTUS_SOLVE_TPB / 2); else RTUS_SOLVE_LAUNCH(false, true, RTUS_SOLVE_TPB / 2); }
+    if (trio && masks) {
+        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, true, RTUS_SOLVE_TPB / 8, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+        else hipLaunchKernelGGL((rtus_solve_kernel<false, true, RTUS_SOLVE_TPB / 8, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+    } else if (trio) {
+        if (fast) hipLaunchKernelGGL((rtus_solve_kernel<true, false, RTUS_SOLVE_TPB, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+        else hipLaunchKernelGGL((rtus_solve_kernel<false, false, RTUS_SOLVE_TPB, true>), grid, dim3(RTUS_SOLVE_TPB), 0, s, q);
+    } else if (half) { if (fast) RTUS_SOLVE_LAUNCH(true, true, RTUS_SOLVE_TPB / 2); else RTUS_SOLVE_LAUNCH(false, true, RTUS_SOLVE_TPB / 2); }
     else if (masks) { if (fast) RTUS_SOLVE_LAUNCH(true, true, RTUS_SOLVE_TPB); else RTUS_SOLVE_LAUNCH(false, true, RTUS_SOLVE_TPB); }
     else { if (fast) RTUS_SOLVE_LAUNCH(true, false, RTUS_SOLVE_TPB); else RTUS_SOLVE_LAUNCH(false, false, RTUS_SOLVE_TPB); }
 #undef RTUS_SOLVE_LAUNCH

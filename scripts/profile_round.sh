@@ -5,7 +5,7 @@
 # rocprofv3 rules of this pool: run from /tmp with TMPDIR=/tmp, the program itself right after `--`, counters in their
 # own passes (never together with a trace domain other than --kernel-trace).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -28,6 +28,13 @@ echo "[4] SQ counters of the headline kernel"
 rocprofv3 --pmc $SQ -d $OUT/sq -o sq --output-format csv -- python3 $B $PMC > $OUT/sq.log 2>&1
 rocprofv3 --pmc $SQ2 -d $OUT/sq2 -o sq --output-format csv -- python3 $B $PMC > $OUT/sq2.log 2>&1
 rocprofv3 --pmc $SQ3 -d $OUT/sq3 -o sq --output-format csv -- python3 $B $PMC > $OUT/sq3.log 2>&1
+if [ -f $ROOT/variants/librtus_persist.so ]; then
+echo "[4b] the headline kernel as a persistent grid (experiment build): SQ counters + its bench line"
+export RTUS_LIB=$ROOT/variants/librtus_persist.so
+rocprofv3 --pmc $SQ -d $OUT/sq_persist -o sq --output-format csv -- python3 $B $PMC > $OUT/sq_persist.log 2>&1
+python3 $B --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $OUT/bench_persist.json 2> $OUT/bench_persist.err
+unset RTUS_LIB
+fi
 echo "[5] the multi-GPU headline's kernel on one GPU (configs[3] shard of 8: 128 rows) and configs[1]"
 for wl in cfg4_lens_f32 cfg2_planar cfg5_fmc; do
   rocprofv3 --pmc $SQ -d $OUT/sq_$wl -o sq --output-format csv -- python3 $B --workload $wl $PMC > $OUT/sq_$wl.log 2>&1

@@ -149,7 +149,7 @@ valu["cfg3_planar"] = {
     "insts_lds_per_solve": round(c.get("SQ_INSTS_LDS", 0) / wave_solves, 2),
     "issue_cycles_per_wave_solve": round(issue / wave_solves, 1),
     "issue_cycles_how": "instruction classes (SQ_INSTS_VALU_*) x issue cycles per wave-instruction measured by scripts/ubench_issue*.hip "
-                        "(profiles/%s_ubench_issue.txt)" % tag,
+                        "(profiles/r02_ubench_issue.txt)",
     "valu_active_frac_of_wave_life": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
     "waves": int(waves), "waves_per_simd_launched": round(waves / 1024.0, 1),
     "valu_active_x_resident_waves": round(8 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3),
@@ -159,6 +159,24 @@ valu["cfg3_planar"] = {
     "clock_ghz": round(clock, 3),
     "clock_how": "GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the counter pass (reads a few % high on dispatches this short)",
 }
+# round 4: the same kernel as a PERSISTENT grid (-DRTUS_EXP_PERSIST, variants/librtus_persist.so): are half-empty wave slots the headline's bound?
+if os.path.isdir(os.path.join(src, "sq_persist")):
+    tp, mp = counters(["sq_persist"], HEAD)
+    cp = next(iter(tp.values())) if tp else {}
+    if cp.get("SQ_WAVE_CYCLES"):
+        clk = clock
+        ns = cp["_duration_ns:SQ_WAVE_CYCLES"]
+        valu["cfg3_planar_persistent_grid_experiment"] = {
+            "build": "-DRTUS_EXP_PERSIST: 2,048 workgroups (8 per CU), each takes work items w, w + 2048, ... (the product launches 4,096 workgroups in two rounds)",
+            "waves": int(cp["SQ_WAVES"]), "insts_valu": int(cp["SQ_INSTS_VALU"]),
+            "wave_life_us_mean": round(4 * cp["SQ_WAVE_CYCLES"] / cp["SQ_WAVES"] / (clk * 1e3), 2),
+            "wave_slots_occupied_frac_of_kernel": round((4 * cp["SQ_WAVE_CYCLES"] / (clk * 1e9)) / (8 * 1024 * ns * 1e-9), 3),
+            "profiled_launch_us": round(ns / 1e3, 1),
+            "product_profiled_launch_us": valu["cfg3_planar"]["profiled_launch_us"],
+            "product_wave_slots_occupied_frac_of_kernel": valu["cfg3_planar"]["wave_slots_occupied_frac_of_kernel"],
+            "reading": "full wave slots do not shorten the launch: the kernel is bound by VALU issue (roofline_valu.frac_of_issue_bound), not by residency",
+        }
+        write_counters(os.path.join(dst, f"{tag}_pmc_sq_cfg3_persist.csv"), tp, mp)
 json.dump(valu, open(os.path.join(dst, f"valu_{tag}.json"), "w"), indent=1)
 for wl, like in (("cfg4_lens_f32", "rtus_tt_lens_kernel"), ("cfg2_planar", "rtus_tt_layers_kernel"), ("cfg5_fmc", "rtus_tt_layers_kernel")):
     t, m = counters([f"sq_{wl}"], like)

@@ -40,7 +40,10 @@ static int bisect(Ctx *c, double a, double fa, double b, double fb, double *root
     fm = F(c, *root, T);
     return fabs(fm) < 1e-9;
 }
-static double DSCALE = 4.0, DMIN = 1e-7, DMAX = 2e-4;
+static double DSCALE = 4.0, DMIN = 3e-6, DMAX = 1e-4, DACC = 1e-8, D2 = 3e-9, UMAX = 2.0;
+/* the rule the kernel uses (rtus_solve_kernel<., ., ., true>): every round evaluates cand - d, cand, cand + d; the root of the inverse
+ * quadratic through the three is ACCEPTED when d <= DACC (x_land has kinks where the return ray moves to the next polyline chord:
+ * a wide triple that straddles one is off by d x the slope's jump), otherwise it is the next candidate with d = D2 */
 static int three(Ctx *c, const double *alpha, const double *land, int br, int n, double *root, double *Tr, int *rounds)
 {
     double xlo = alpha[br], xhi = alpha[br + 1], flo = land[br] - c->xe, fhi = land[br + 1] - c->xe;
@@ -54,34 +57,34 @@ static int three(Ctx *c, const double *alpha, const double *land, int br, int n,
     const double sec = xlo - flo * (xhi - xlo) / (fhi - flo);
     if (!(cand > xlo && cand < xhi)) cand = sec;
     if (!(cand > xlo && cand < xhi)) cand = 0.5 * (xlo + xhi);
-    /* how far the candidate may be off: a fraction of what the quadratic term moved it from the secant's zero */
     double d = fmin(fmax(DSCALE * 0.02 * fabs(cand - sec), DMIN), DMAX);
     if (single) { cand = (fhi == 0.0 || fabs(fhi) < fabs(flo)) ? xhi : xlo; double T; double f = F(c, cand, &T); *rounds = 1; *root = cand; *Tr = T; return isfinite(f) && fabs(f) < 1e-9; }
-    for (int rd = 1; rd <= 30; ++rd) {
+    double fprev = INFINITY;
+    for (int rd = 1; rd <= 40; ++rd) {
         d = fmin(d, 0.999 * fmin(cand - xlo, xhi - cand));
         double T0, Tm, Tq;
         const double f0 = F(c, cand, &T0), fm = F(c, cand - d, &Tm), fq = F(c, cand + d, &Tq);
         *rounds = rd;
-        if (!isfinite(f0) || !isfinite(fm) || !isfinite(fq)) return 0;             /* the branch ends inside the bracket */
+        if (getenv("P3_TRACE") && c->evals > 0 && rd >= 1 && c->r == atof(getenv("P3_R")) && fabs(c->off - atof(getenv("P3_OFF"))) < 1e-9 && br == atoi(getenv("P3_Q"))) printf("  rd %d cand %.12f d %.3g fm %.3e f0 %.3e fq %.3e bracket [%.12f, %.12f]\n", rd, cand, d, fm, f0, fq, xlo, xhi);
+        if (!isfinite(f0)) return 0;                                                /* the branch ends inside the bracket */
         if (f0 == 0.0) { *root = cand; *Tr = T0; return 1; }
-        const int mono = (fq - f0) * (f0 - fm) > 0.0;
+        const int fin3 = isfinite(fm) && isfinite(fq);
+        const int mono = fin3 && (fq - f0) * (f0 - fm) > 0.0;
+        double x3 = NAN;
         if (mono && d > 0) {
-            const double x3 = iqi(cand, f0, cand - d, fm, cand + d, fq), u = (x3 - cand) / d;
-            if (fabs(u) <= 2.0) {
-                *root = x3;
-                *Tr = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm)));
-                return 1;
-            }
+            x3 = iqi(cand, f0, cand - d, fm, cand + d, fq);
+            const double u = (x3 - cand) / d;
+            if ((d <= DACC && fabs(u) <= UMAX) || (rd >= 2 && fabs(f0) <= 1e-9 && fabs(x3 - cand) <= 1e-8)) { *root = x3; *Tr = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm))); return 1; }
         }
-        /* the root is not next to the three points: they tighten the bracket, the next candidate comes from them */
         const double xs[3] = {cand - d, cand, cand + d}, fs[3] = {fm, f0, fq};
-        for (int i = 0; i < 3; ++i) { if ((fs[i] < 0) == (flo < 0)) { if (xs[i] > xlo) { xlo = xs[i]; flo = fs[i]; } } else if (xs[i] < xhi) { xhi = xs[i]; fhi = fs[i]; } }
-        double nc = mono ? iqi(cand, f0, cand - d, fm, cand + d, fq) : NAN;
+        for (int i = 0; i < 3; ++i) { if (!isfinite(fs[i])) continue; if ((fs[i] < 0) == (flo < 0)) { if (xs[i] > xlo) { xlo = xs[i]; flo = fs[i]; } } else if (xs[i] < xhi) { xhi = xs[i]; fhi = fs[i]; } }
+        if (xhi - xlo <= 1e-13) { *root = cand; *Tr = T0; return fabs(f0) < 1e-9; }  /* a jump, or the root itself */
+        double nc = x3;
         if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) / (fhi - flo);
-        if (!(nc > xlo && nc < xhi)) nc = 0.5 * (xlo + xhi);
-        d = fmin(fmax(0.05 * fabs(nc - cand), 1e-9), DMAX);
+        if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev) { nc = 0.5 * (xlo + xhi); d = 0.25 * (xhi - xlo); }
+        else d = fmax(fmin(fmax(D2, fmin(1e-4 * d, DACC)), 0.25 * fabs(nc - cand)), 1e-11);
+        fprev = fabs(f0);
         cand = nc;
-        if (xhi - xlo < 1e-14) { double T; double f = F(c, cand, &T); *root = cand; *Tr = T; return isfinite(f) && fabs(f) < 1e-9; }
     }
     return 0;
 }
@@ -91,6 +94,8 @@ int main(int argc, char **argv)
     if (argc > 1) DSCALE = atof(argv[1]);
     if (argc > 2) DMIN = atof(argv[2]);
     if (argc > 3) DMAX = atof(argv[3]);
+    if (argc > 4) UMAX = atof(argv[4]);
+    if (argc > 5) D2 = atof(argv[5]);
     orc_lens L = {6400.0, 1483.0, 0.12156646438729327, 0.08843353561270673, 0};
     L.d = L.l0 + L.h0;
     const int n = 905, ne = 65;
@@ -119,13 +124,14 @@ int main(int argc, char **argv)
                 const int okb = bisect(&c, alpha[q], f0, alpha[q + 1], f1, &rb, &Tb);
                 const int ok3 = three(&c, alpha, land, q, n, &r3, &T3, &rounds);
                 hist[rounds < 31 ? rounds : 31]++;
+                if (rounds >= 4 && getenv("P3_LIST")) printf("SLOW r=%.2f off=%.3f tx=%g e=%d q=%d rounds %d f0=%g f1=%g\n", r, off, txs[t], e, q, rounds, f0, f1);
                 if (okb == ok3) { ++agree; if (okb) { ++nroot; const int degenerate = oi == 0 && txs[t] == 0.0;   /* every ray retraces itself: a continuum of roots */
                     if (!degenerate) { if (fabs(rb - r3) > worst_a) worst_a = fabs(rb - r3); if (fabs(Tb - T3) > worst_t) worst_t = fabs(Tb - T3); if (fabs(rb - r3) > 1e-11 || fabs(Tb - T3) > 1e-13) { ++nbig; if (nbig < 8) printf("BIG r=%.2f off=%.3f tx=%g e=%d q=%d rounds %d dalpha %.3g dT %.3g\n", r, off, txs[t], e, q, rounds, rb - r3, Tb - T3); } } } }
                 else { ++disagree; if (disagree < 12) printf("DISAGREE r=%.2f off=%.3f tx=%g e=%d q=%d bisect=%d three=%d (%d rounds) f0=%g f1=%g\n", r, off, txs[t], e, q, okb, ok3, rounds, f0, f1); }
             }
         }
     }
-    printf("d = clamp(%g x 0.02 |iqi - secant|, %g, %g): brackets %ld, roots %ld, agree %ld disagree %ld; worst |dalpha| %.3g rad, worst |dT| %.3g s\n", DSCALE, DMIN, DMAX, nbr, nroot, agree, disagree, worst_a, worst_t);
+    printf("d1 = clamp(%g x 0.02 |iqi - secant|, %g, %g), accept at d <= 2e-8: brackets %ld, roots %ld, agree %ld disagree %ld; worst |dalpha| %.3g rad, worst |dT| %.3g s\n", DSCALE, DMIN, DMAX, nbr, nroot, agree, disagree, worst_a, worst_t);
     printf("beyond 1e-11 rad or 1e-13 s (degenerate continuum excluded): %ld\n", nbig);
     printf("rounds:"); for (int i = 0; i < 32; ++i) if (hist[i]) printf("  %d: %ld", i, hist[i]); printf("\n");
     return 0;
