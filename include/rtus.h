@@ -187,6 +187,10 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
  * against bisection); within one scheme a bracket's bits do not depend on the aperture's order or on the other brackets of the
  * call.  RTUS_SOLVE_ONE_LANE asks for the one-lane scheme whatever the size (bits independent of the call's size too). */
 #define RTUS_SOLVE_ONE_LANE 0x10u
+/* Such a small call with a grid of <= 1,024 rays and <= 128 elements (the reference's sweep: 905, 65) runs as ONE kernel after the
+ * polyline's — a workgroup per (geometry, transmit point) row, landing points and pair masks in LDS.  RTUS_SOLVE_THREE_LAUNCHES
+ * keeps the grid trace and the refinement as separate launches (the same bits: the refinement's arithmetic is one function). */
+#define RTUS_SOLVE_THREE_LAUNCHES 0x20u
 
 size_t rtus_solve_workspace_bytes(int n_rays, int n_geom, int n_tx, int n_rx);
 

@@ -359,10 +359,11 @@ def fmc_table_layers(z_if, c, x_tx, x_rx, z_reflector, *, z_array=0.0, device=0,
 
 
 SOLVE_ONE_LANE = 0x10       # RTUS_SOLVE_ONE_LANE (include/rtus.h)
+SOLVE_THREE_LAUNCHES = 0x20
 
 
 def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params: Params = None, fast=False,
-                       true_tangent=False, analytic_lens=False, all_roots=False, one_lane=False, device=0):
+                       true_tangent=False, analytic_lens=False, all_roots=False, one_lane=False, three_launches=False, device=0):
     """Pulse-echo travel times tx -> lens -> pipe -> lens -> rx by root-finding x_land(alpha) = x_rx — the
     replacement for the reference's grid scan + tolerance matcher (main_rt.py:479-501).
 
@@ -392,7 +393,8 @@ def solve_travel_times(x_a, z_a, x_rx, alpha, geoms=None, *, z_land=None, params
     lens = p.lens()
     st = _lib.lib().rtus_solve(C.byref(lens), _ptr(geoms), G, _ptr(x_a), _ptr(z_a), T, _ptr(alpha), alpha.size,
                                _ptr(x_rx), E, z_land, _ptr(tt), _ptr(ar), _ptr(ta), _ptr(aa), _ptr(nr),
-                               _flags(fast, true_tangent, analytic_lens) | (SOLVE_ONE_LANE if one_lane else 0), int(device))
+                               _flags(fast, true_tangent, analytic_lens) | (SOLVE_ONE_LANE if one_lane else 0) | (SOLVE_THREE_LAUNCHES if three_launches else 0),
+                               int(device))
     _lib.check(st, "rtus_solve")
     return (tt, ar, ta, aa, nr) if all_roots else (tt, ar)
 

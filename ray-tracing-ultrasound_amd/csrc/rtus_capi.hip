@@ -416,7 +416,7 @@ static int check_solve(const rtus_lens* lens, const void* geoms, int n_geom, con
     int st = check_shoot(lens, geoms, n_geom, x_a, z_a, n_tx, alpha, alpha, n_rays);
     if (st) return st;
     if (!x_rx || !tt || n_rx <= 0 || !isfinite(z_land)) return RTUS_ERR_INVALID_ARG;
-    if (flags & ~(RTUS_SHOOT_KNOWN_FLAGS | RTUS_SOLVE_ONE_LANE)) return RTUS_ERR_INVALID_ARG;
+    if (flags & ~(RTUS_SHOOT_KNOWN_FLAGS | RTUS_SOLVE_ONE_LANE | RTUS_SOLVE_THREE_LAUNCHES)) return RTUS_ERR_INVALID_ARG;
     if ((long long)n_geom * n_tx > 0x7fffffffLL / (n_rx > 0 ? n_rx : 1)) return RTUS_ERR_UNSUPPORTED;
     if ((long long)n_geom * n_tx * ((n_rays + 63) / 64) > 0x7fffffffLL) return RTUS_ERR_UNSUPPORTED;
     return RTUS_OK;

@@ -335,6 +335,9 @@ static void rtus_launch_geometry(const ShootArgs& a, const double* alpha, hipStr
 }
 
 // z_f == nullptr: every ray lands on z = zf_const; land_box: optional per-wave (min, max) of the landing points (the solve)
+// the polyline, tangents, boxes and box records of `alpha` into the workspace `a` points to (rtus_solve's one-launch path)
+void rtus_launch_geometry_only(const ShootArgs& a, const double* alpha, hipStream_t s) { rtus_launch_geometry(a, alpha, s); }
+
 hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int n_geom, const double* x_a,
                                        const double* z_a, int n_tx, const double* alpha, const double* z_f, double zf_const, int n,
                                        double* out8, double* tof4, double* tof, double* land_x, uint8_t* status,

@@ -96,6 +96,103 @@ __device__ __forceinline__ double solve_iqi(double xa, double fa, double xb, dou
 // about one bracket per element the list then fits ONE trip of the four waves even where elements have two (a list of 260
 // brackets on 256 lanes costs its workgroup a second trip for four of them — in a launch of a few hundred waves that trip is
 // the kernel's critical path).  The launcher takes 128 for launches that leave SIMDs idle anyway.
+// The three-lanes-per-bracket refinement of ONE trip of a wave (see rtus_solve_kernel's TRIO comment): lanes 3 jb, 3 jb + 1, 3 jb + 2
+// hold bracket `br` of the row whose grid landing points are `lrow` (global memory, or LDS in the one-launch kernel) and trace
+// cand - d, cand, cand + d; `tri` is this wave's [64][2] exchange buffer in LDS.  All lanes of the wave call it together.
+template <bool FAST>
+__device__ __forceinline__ void trio_refine(const SolveArgs& q, const ShootArgs& a, const LensK& k, const double* lrow, RayIn in, double xr,
+                                            int br, int n, int lane, int jb, int role, double (*tri)[2], bool& root, double& T_out,
+                                            double& x_out)
+{
+    double xlo = q.alpha[br], xhi = q.alpha[br + 1];
+    double flo = lrow[br] - xr, fhi = lrow[br + 1] - xr;
+    double xt, ft;                                                   // third grid ray: as in the one-lane scheme below
+    {
+        const bool left = fabs(flo) < fabs(fhi);
+        const int t1 = left ? br - 1 : br + 2, t2 = left ? br + 2 : br - 1;
+        const int c1 = min(max(t1, 0), n - 1), c2 = min(max(t2, 0), n - 1);
+        const double l1 = lrow[c1], l2 = lrow[c2];
+        const bool ok1 = c1 == t1 && isfinite(l1), ok2 = c2 == t2 && isfinite(l2);
+        xt = q.alpha[ok1 ? c1 : c2];
+        ft = (ok1 ? l1 : (ok2 ? l2 : NAN)) - xr;
+    }
+    const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
+    const double sec = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
+    double cand = solve_iqi(xlo, flo, xhi, fhi, xt, ft);             // NaN without a third ray
+    if (!(cand > xlo && cand < xhi)) cand = sec;
+    if (!(cand > xlo && cand < xhi)) cand = 0.5 * (xlo + xhi);
+    // how far the candidate may be off: a fraction of what the quadratic term moved it from the secant's zero
+    double delta = fmin(fmax(0.08 * fabs(cand - sec), 3e-6), 1e-4);
+    if (single) { cand = (fhi == 0.0 || fabs(fhi) < fabs(flo)) ? xhi : xlo; delta = 0.0; }
+    double fprev_abs = INFINITY;
+    double x_fin = NAN, T_fin = NAN, f_fin = NAN;
+    bool done = false, dead = false;
+    for (int it = 0; it < 48; ++it) {
+        if (!__any(!done)) break;
+        STAMP(3 + min(it, 9));
+        if (!single) delta = fmin(delta, 0.999 * fmin(cand - xlo, xhi - cand));
+        const double ac = cand + (double)(role - 1) * delta;
+        double sn, cs, px, pz, dz, dx;
+        rtus_sincos(ac, sn, cs);
+        lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
+        in.P = make_double2(px, pz);
+        { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
+        if (!FAST) in.phis = rtus_atan2(dz, dx);
+        RayOut o;
+        trace_ray<FAST>(a, in, o);                                   // all 64 lanes together
+        const double t1 = seg_time<FAST>(in.xa, in.za, px, pz, k.c1, k.inv_c1);
+        const double t2 = seg_time<FAST>(px, pz, o.xq, o.zq, k.c2, k.inv_c2);
+        const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
+        const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
+        tri[lane][0] = o.x_in - xr;
+        tri[lane][1] = ((t1 + t2) + t3) + t4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double fm = tri[3 * jb][0], f0 = tri[3 * jb + 1][0], fq = tri[3 * jb + 2][0];
+        const double Tm = tri[3 * jb][1], T0 = tri[3 * jb + 1][1], Tq = tri[3 * jb + 2][1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!done) {                                                 // (the three lanes of a bracket decide alike: same inputs)
+            if (!isfinite(f0)) { dead = true; done = true; }         // the branch ends inside the bracket
+            else if (single || f0 == 0.0) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }
+            else {
+                const bool mono = isfinite(fm) && isfinite(fq) && (fq - f0) * (f0 - fm) > 0.0 && delta > 0.0;
+                double x3 = NAN;
+                if (mono) {
+                    x3 = solve_iqi(cand, f0, cand - delta, fm, cand + delta, fq);
+                    const double u = (x3 - cand) * solve_rcp(delta);
+                    if (delta <= 1e-8 && fabs(u) <= 8.0) {       // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad)
+                        done = true;
+                        f_fin = 0.0;                                 // a root next to three fresh points
+                        x_fin = x3;
+                        T_fin = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm)));
+                    }
+                }
+                if (!done) {
+                    // the three points tighten the bracket; the next centre comes from them
+                    const double xs0 = cand - delta, xs2 = cand + delta;
+                    if (isfinite(fm)) { if ((fm < 0.0) == (flo < 0.0)) { if (xs0 > xlo) { xlo = xs0; flo = fm; } } else if (xs0 < xhi) { xhi = xs0; fhi = fm; } }
+                    { if ((f0 < 0.0) == (flo < 0.0)) { if (cand > xlo) { xlo = cand; flo = f0; } } else if (cand < xhi) { xhi = cand; fhi = f0; } }
+                    if (isfinite(fq)) { if ((fq < 0.0) == (flo < 0.0)) { if (xs2 > xlo) { xlo = xs2; flo = fq; } } else if (xs2 < xhi) { xhi = xs2; fhi = fq; } }
+                    if (xhi - xlo <= 1e-13) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }      // a jump — or the root itself
+                    else {
+                        double nc = x3;
+                        if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
+                        if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev_abs) { nc = 0.5 * (xlo + xhi); delta = 0.25 * (xhi - xlo); }
+                        else delta = fmax(fmin(fmax(3e-9, fmin(1e-4 * delta, 1e-8)), 0.25 * fabs(nc - cand)), 1e-11);   // (a wide first triple may straddle a kink: its zero is good to ~1e-4 d)
+                        fprev_abs = fabs(f0);
+                        x_fin = cand; T_fin = T0; f_fin = f0;        // (what an exhausted iteration reports)
+                        cand = nc;
+                    }
+                }
+            }
+        }
+    }
+    root = done && !dead && fabs(f_fin) < 1e-9;              // |f| large at convergence: a jump, not a root
+    T_out = T_fin; x_out = x_fin;
+}
+
 // TRIO (round 4; small launches only — the launcher's choice is a function of the call's size, so which scheme refines a bracket is
 // too): THREE LANES PER BRACKET.  In a launch that leaves most SIMDs idle the kernel lasts as long as its slowest wave's chain of
 // dependent evaluations (~11 us each), and with one lane per bracket 0.7 % of the brackets — a third of the waves — need a third one.
@@ -273,92 +370,9 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
         RayIn in;
         in.r_outer = a.geoms[2 * g]; in.off = a.geoms[2 * g + 1];
         in.xa = a.x_a[tx]; in.za = a.z_a[tx]; in.zf = q.z_land;
-        double xlo = q.alpha[br], xhi = q.alpha[br + 1];
-        double flo = lrow[br] - xr, fhi = lrow[br + 1] - xr;
-        double xt, ft;                                                   // third grid ray: as in the one-lane scheme below
-        {
-            const bool left = fabs(flo) < fabs(fhi);
-            const int t1 = left ? br - 1 : br + 2, t2 = left ? br + 2 : br - 1;
-            const int c1 = min(max(t1, 0), n - 1), c2 = min(max(t2, 0), n - 1);
-            const double l1 = lrow[c1], l2 = lrow[c2];
-            const bool ok1 = c1 == t1 && isfinite(l1), ok2 = c2 == t2 && isfinite(l2);
-            xt = q.alpha[ok1 ? c1 : c2];
-            ft = (ok1 ? l1 : (ok2 ? l2 : NAN)) - xr;
-        }
-        const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
-        const double sec = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
-        double cand = solve_iqi(xlo, flo, xhi, fhi, xt, ft);             // NaN without a third ray
-        if (!(cand > xlo && cand < xhi)) cand = sec;
-        if (!(cand > xlo && cand < xhi)) cand = 0.5 * (xlo + xhi);
-        // how far the candidate may be off: a fraction of what the quadratic term moved it from the secant's zero
-        double delta = fmin(fmax(0.08 * fabs(cand - sec), 3e-6), 1e-4);
-        if (single) { cand = (fhi == 0.0 || fabs(fhi) < fabs(flo)) ? xhi : xlo; delta = 0.0; }
-        double fprev_abs = INFINITY;
-        double x_fin = NAN, T_fin = NAN, f_fin = NAN;
-        bool done = false, dead = false;
-        for (int it = 0; it < 48; ++it) {
-            if (!__any(!done)) break;
-            STAMP(3 + min(it, 9));
-            if (!single) delta = fmin(delta, 0.999 * fmin(cand - xlo, xhi - cand));
-            const double ac = cand + (double)(role - 1) * delta;
-            double sn, cs, px, pz, dz, dx;
-            rtus_sincos(ac, sn, cs);
-            lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
-            in.P = make_double2(px, pz);
-            { const double rt = rsqrt_fast(dx * dx + dz * dz); in.tu = make_double2(dx * rt, dz * rt); }
-            if (!FAST) in.phis = rtus_atan2(dz, dx);
-            RayOut o;
-            trace_ray<FAST>(a, in, o);                                   // all 64 lanes together
-            const double t1 = seg_time<FAST>(in.xa, in.za, px, pz, k.c1, k.inv_c1);
-            const double t2 = seg_time<FAST>(px, pz, o.xq, o.zq, k.c2, k.inv_c2);
-            const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
-            const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
-            tri[wv][lane][0] = o.x_in - xr;
-            tri[wv][lane][1] = ((t1 + t2) + t3) + t4;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double fm = tri[wv][3 * jb][0], f0 = tri[wv][3 * jb + 1][0], fq = tri[wv][3 * jb + 2][0];
-            const double Tm = tri[wv][3 * jb][1], T0 = tri[wv][3 * jb + 1][1], Tq = tri[wv][3 * jb + 2][1];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (!done) {                                                 // (the three lanes of a bracket decide alike: same inputs)
-                if (!isfinite(f0)) { dead = true; done = true; }         // the branch ends inside the bracket
-                else if (single || f0 == 0.0) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }
-                else {
-                    const bool mono = isfinite(fm) && isfinite(fq) && (fq - f0) * (f0 - fm) > 0.0 && delta > 0.0;
-                    double x3 = NAN;
-                    if (mono) {
-                        x3 = solve_iqi(cand, f0, cand - delta, fm, cand + delta, fq);
-                        const double u = (x3 - cand) * solve_rcp(delta);
-                        if (delta <= 1e-8 && fabs(u) <= 8.0) {       // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad)
-                            done = true;
-                            f_fin = 0.0;                                 // a root next to three fresh points
-                            x_fin = x3;
-                            T_fin = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm)));
-                        }
-                    }
-                    if (!done) {
-                        // the three points tighten the bracket; the next centre comes from them
-                        const double xs0 = cand - delta, xs2 = cand + delta;
-                        if (isfinite(fm)) { if ((fm < 0.0) == (flo < 0.0)) { if (xs0 > xlo) { xlo = xs0; flo = fm; } } else if (xs0 < xhi) { xhi = xs0; fhi = fm; } }
-                        { if ((f0 < 0.0) == (flo < 0.0)) { if (cand > xlo) { xlo = cand; flo = f0; } } else if (cand < xhi) { xhi = cand; fhi = f0; } }
-                        if (isfinite(fq)) { if ((fq < 0.0) == (flo < 0.0)) { if (xs2 > xlo) { xlo = xs2; flo = fq; } } else if (xs2 < xhi) { xhi = xs2; fhi = fq; } }
-                        if (xhi - xlo <= 1e-13) { done = true; x_fin = cand; T_fin = T0; f_fin = f0; }      // a jump — or the root itself
-                        else {
-                            double nc = x3;
-                            if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
-                            if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev_abs) { nc = 0.5 * (xlo + xhi); delta = 0.25 * (xhi - xlo); }
-                            else delta = fmax(fmin(fmax(3e-9, fmin(1e-4 * delta, 1e-8)), 0.25 * fabs(nc - cand)), 1e-11);   // (a wide first triple may straddle a kink: its zero is good to ~1e-4 d)
-                            fprev_abs = fabs(f0);
-                            x_fin = cand; T_fin = T0; f_fin = f0;        // (what an exhausted iteration reports)
-                            cand = nc;
-                        }
-                    }
-                }
-            }
-        }
-        const bool root = done && !dead && fabs(f_fin) < 1e-9;           // |f| large at convergence: a jump, not a root
+        bool root;
+        double T_fin, x_fin;
+        trio_refine<FAST>(q, a, k, lrow, in, xr, br, n, lane, jb, role, tri[wv], root, T_fin, x_fin);
         if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
     }
     } else {
@@ -562,6 +576,176 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     STAMP(15);
 }
 
+// ---- ONE LAUNCH per pass at the reference's size (round 4) ----------------------------------------------------------------------
+// A workgroup of 1,024 threads = ONE ROW (geometry, transmit point) from the grid trace to the stored roots: thread r traces grid
+// ray r (n <= 1,024: the reference's sweep has 905), the landing points and the pair masks stay in LDS (no round trip through
+// global memory, no kernel boundary between the trace and the refinement: a row starts refining as soon as ITS rays are down,
+// not when the slowest wave of the whole grid trace is), the first n_rx <= 128 threads are the element lanes, and all sixteen
+// waves refine the row's brackets three lanes per bracket (trio_refine: the same arithmetic — the same bits — as
+// rtus_solve_kernel<., ., ., true>).  The polyline and its box records come from rtus_geom1_kernel as before (a separate launch
+// the caller skips with RTUS_POLYLINE_READY).
+#define RTUS_ROW_TPB 1024
+#define RTUS_ROW_WAVES (RTUS_ROW_TPB / 64)
+#define RTUS_ROW_MAX_RX 128
+template <bool FAST>
+__global__ __launch_bounds__(RTUS_ROW_TPB) void rtus_solve_row_kernel(SolveArgs q)
+{
+    __shared__ double land_s[RTUS_ROW_TPB + 1];
+    __shared__ unsigned long long mask_s[RTUS_ROW_TPB / 64][RTUS_ROW_MAX_RX];
+    __shared__ unsigned items[RTUS_ROW_MAX_RX * RTUS_MAX_ROOTS];
+    __shared__ int item_r[RTUS_ROW_MAX_RX * RTUS_MAX_ROOTS];
+    __shared__ double res_t[RTUS_ROW_MAX_RX * RTUS_MAX_ROOTS], res_a[RTUS_ROW_MAX_RX * RTUS_MAX_ROOTS];
+    __shared__ int wave_tot[RTUS_ROW_WAVES];
+    __shared__ double tri[RTUS_ROW_WAVES][64][2];
+    const ShootArgs& a = q.s;
+    const LensK& k = a.k;
+    const int n = a.n, nb = (n + 63) >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long row = blockIdx.x;
+    const int g = (int)(row / a.n_tx), tx = (int)(row - (long long)g * a.n_tx);
+    RayIn in0;
+    in0.r_outer = a.geoms[2 * g]; in0.off = a.geoms[2 * g + 1];
+    in0.xa = a.x_a[tx]; in0.za = a.z_a[tx]; in0.zf = q.z_land;
+
+    // ---- the grid trace: thread r = ray r (threads past the grid redo its last ray, so that waves stay whole) ----------------------
+    {
+        const int r_raw = threadIdx.x;
+        const bool live = r_raw < n;
+        const int r = live ? r_raw : n - 1;
+        RayIn in = in0;
+        in.P = a.curve[r];
+        in.tu = a.tan_u[r];
+        if (!FAST) in.phis = a.phi_s[r];
+        RayOut o;
+        trace_ray<FAST>(a, in, o);
+        const double x_in = o.x_in;
+        land_s[threadIdx.x] = live ? x_in : NAN;
+        if (threadIdx.x == 0) land_s[RTUS_ROW_TPB] = NAN;
+        // which elements each pair of consecutive rays brackets: rtus_shoot_kernel<., true>'s emission, into LDS
+        const double l0 = live ? x_in : NAN;
+        double l1 = __shfl_down(l0, 1);
+        l1 = lane == 63 ? NAN : l1;
+        const double plo = (l0 == l0 && l1 == l1) ? fmin(l0, l1) : NAN, phi = (l0 == l0 && l1 == l1) ? fmax(l0, l1) : NAN;
+        const bool pv = isfinite(plo) && isfinite(phi);
+        double wlo = pv ? plo : INFINITY, whi = pv ? phi : -INFINITY;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { wlo = fmin(wlo, __shfl_xor(wlo, o2)); whi = fmax(whi, __shfl_xor(whi, o2)); }
+        for (int c0 = 0; c0 < q.rx_pad; c0 += 64) {
+            const bool ev = c0 + lane < q.n_rx;
+            const double xv = q.x_rx[min(c0 + lane, q.n_rx - 1)];
+            const double xn = __shfl_down(xv, 1);
+            const bool asc = !__ballot(ev && lane < 63 && c0 + lane + 1 < q.n_rx && !(xv <= xn));
+            const int nlo = __popcll(__ballot(ev && xv < wlo)), nhi = __popcll(__ballot(ev && xv <= whi));
+            const int e0 = asc ? nlo : 0, e1 = asc ? nhi : min(64, q.n_rx - c0);
+            unsigned long long mine = 0;
+            for (int e = e0; e < e1; ++e) {
+                const double x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xv), e), __builtin_amdgcn_readlane(__double2loint(xv), e));
+                const lanemask m = __ballot(plo <= x && x <= phi && x != l0);
+                mine = lane == e ? m : mine;
+            }
+            mask_s[wv][c0 + lane] = mine;
+        }
+    }
+    __syncthreads();
+
+    // ---- A: the element lanes (threads 0 .. n_rx - 1) take their brackets from the masks, in ascending alpha -------------------
+    const bool live = (int)threadIdx.x < q.n_rx;
+    const int e = live ? (int)threadIdx.x : q.n_rx - 1;
+    const double xe = q.x_rx[e];
+    int b0 = -1, b1 = -1, b2 = -1, b3 = -1, cnt = 0;
+    auto add_bracket = [&](bool yes, int r) {
+        if (yes) {
+            b0 = cnt == 0 ? r : b0; b1 = cnt == 1 ? r : b1;
+            b2 = cnt == 2 ? r : b2; b3 = cnt == 3 ? r : b3;
+            ++cnt;
+        }
+    };
+    if (wv < (q.n_rx + 63) / 64) {                                       // wave-uniform
+        for (int B = 0; B < nb; ++B) {
+            unsigned long long m = mask_s[B][e];
+            const int rb = B * 64;
+            while (__any(m != 0ull && cnt < RTUS_MAX_ROOTS)) {
+                const bool has = m != 0ull;
+                add_bracket(has, rb + (int)__builtin_ctzll(has ? m : 1ull));
+                m &= m - 1ull;
+            }
+            const double la = land_s[min(rb + 63, n - 1)], lb = land_s[min(rb + 64, n - 1)];    // the pair that straddles blocks B, B + 1
+            const bool edge = rb + 64 < n && isfinite(la) && isfinite(lb) && ((la < xe && xe <= lb) || (la > xe && xe >= lb));
+            add_bracket(edge, rb + 63);
+        }
+    }
+    cnt = live ? min(cnt, RTUS_MAX_ROOTS) : 0;
+
+    // ---- B: one list of the row's brackets, in (element, bracket) order -------------------------------------------------------------
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        const lanemask mj = __ballot(cnt > j);
+        pre += __builtin_amdgcn_mbcnt_hi((unsigned)(mj >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mj, 0));
+        tot += __popcll(mj);
+    }
+    if (lane == 0) wave_tot[wv] = tot;
+    if ((int)threadIdx.x < RTUS_ROW_MAX_RX) {
+#pragma unroll
+        for (int j = 0; j < RTUS_MAX_ROOTS; ++j) { res_t[threadIdx.x * RTUS_MAX_ROOTS + j] = NAN; res_a[threadIdx.x * RTUS_MAX_ROOTS + j] = NAN; }
+    }
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < RTUS_ROW_WAVES; ++w) { const int tw = wave_tot[w]; base += w < wv ? tw : 0; total += tw; }
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        if (j < cnt) {
+            items[base + pre + j] = (unsigned)threadIdx.x * RTUS_MAX_ROOTS + j;
+            item_r[base + pre + j] = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+        }
+    }
+    __syncthreads();
+
+    // ---- C: three lanes per bracket, 21 brackets per wave and trip ------------------------------------------------------------------
+    for (int i0 = wv * RTUS_TRIO_PER_WAVE; i0 < total; i0 += RTUS_ROW_WAVES * RTUS_TRIO_PER_WAVE) {   // wave-uniform
+        const int jb = min(lane / 3, RTUS_TRIO_PER_WAVE - 1), role = lane - 3 * (lane / 3);
+        const bool mine = i0 + jb < total && lane < 3 * RTUS_TRIO_PER_WAVE && role == 1;
+        const int ii = min(i0 + jb, total - 1);
+        const unsigned slot = items[ii];
+        const int br = item_r[ii];
+        const double xr = q.x_rx[(int)(slot >> 2)];
+        bool root;
+        double T_fin, x_fin;
+        trio_refine<FAST>(q, a, k, land_s, in0, xr, br, n, lane, jb, role, tri[wv], root, T_fin, x_fin);
+        if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
+    }
+    __syncthreads();
+
+    // ---- D: the element lanes collect their roots (ascending alpha, compacted) ------------------------------------------------------
+    if (!live) return;
+    double tmin = NAN, amin = NAN, tk[RTUS_MAX_ROOTS], ak[RTUS_MAX_ROOTS];
+    int nr = 0;
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) { tk[j] = NAN; ak[j] = NAN; }
+#pragma unroll
+    for (int j = 0; j < RTUS_MAX_ROOTS; ++j) {
+        const double T = res_t[threadIdx.x * RTUS_MAX_ROOTS + j], A = res_a[threadIdx.x * RTUS_MAX_ROOTS + j];
+        if (T == T) {
+            tk[0] = nr == 0 ? T : tk[0]; ak[0] = nr == 0 ? A : ak[0];
+            tk[1] = nr == 1 ? T : tk[1]; ak[1] = nr == 1 ? A : ak[1];
+            tk[2] = nr == 2 ? T : tk[2]; ak[2] = nr == 2 ? A : ak[2];
+            tk[3] = nr == 3 ? T : tk[3]; ak[3] = nr == 3 ? A : ak[3];
+            if (!(tmin <= T)) { tmin = T; amin = A; }
+            ++nr;
+        }
+    }
+    const size_t o1 = (size_t)row * q.n_rx + e;
+    q.tt[o1] = tmin;
+    if (q.alpha_root) q.alpha_root[o1] = amin;
+    if (q.n_roots) q.n_roots[o1] = (uint8_t)nr;
+#pragma unroll
+    for (int kk = 0; kk < RTUS_MAX_ROOTS; ++kk) {
+        if (q.tt_all) q.tt_all[o1 * RTUS_MAX_ROOTS + kk] = tk[kk];
+        if (q.alpha_all) q.alpha_all[o1 * RTUS_MAX_ROOTS + kk] = ak[kk];
+    }
+}
+
 // Workspace of the solve = shoot workspace + land_x[rows][n] + land intervals[rows][nb].
 static size_t sws_land_off(int n) { return align32(shoot_ws_bytes(n)); }
 static size_t sws_box_off(int n, int n_geom, int n_tx) { return align32(sws_land_off(n) + (size_t)n_geom * n_tx * (size_t)n * sizeof(double)); }
@@ -581,6 +765,24 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     char* w = (char*)ws;
     double* land = (double*)(w + sws_land_off(n));
     const bool masks = n_rx <= RTUS_SOLVE_MASK_MAX_RX;
+    // small calls with a grid of <= 1,024 rays and <= 128 elements (the reference's own sweep): ONE launch, a workgroup per row
+    const long long rows = (long long)n_geom * n_tx;
+    if (rows * n_rx <= 32768 && n <= RTUS_ROW_TPB && n_rx <= RTUS_ROW_MAX_RX && rows <= 0x7fffffffLL && !(flags & (RTUS_SOLVE_ONE_LANE | RTUS_SOLVE_THREE_LAUNCHES))) {
+        SolveArgs q;
+        ShootArgs& a = q.s;
+        a.k = make_lens_k(lens);
+        a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = nullptr; a.zf_const = z_land;
+        shoot_args_workspace(a, w, n);
+        a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0;
+        a.n_tx = n_tx; a.n_geom = n_geom; a.flags = flags;
+        if (!(flags & RTUS_POLYLINE_READY)) rtus_launch_geometry_only(a, alpha, s);
+        q.alpha = alpha; q.land_x = nullptr; q.land_box = nullptr; q.pair_mask = nullptr; q.rx_pad = (n_rx + 63) & ~63; q.nb = (n + 63) / 64; q.x_rx = x_rx;
+        q.z_land = z_land; q.n_rx = n_rx; q.chunks = (n_rx + 63) / 64; q.n_tasks = rows * n_rx;
+        q.tt = tt; q.alpha_root = alpha_root; q.tt_all = tt_all; q.alpha_all = alpha_all; q.n_roots = n_roots;
+        if (flags & RTUS_SHOOT_FAST_MATH) hipLaunchKernelGGL((rtus_solve_row_kernel<true>), dim3((unsigned)rows), dim3(RTUS_ROW_TPB), 0, s, q);
+        else hipLaunchKernelGGL((rtus_solve_row_kernel<false>), dim3((unsigned)rows), dim3(RTUS_ROW_TPB), 0, s, q);
+        return hipGetLastError();
+    }
     double2* boxes = masks ? nullptr : (double2*)(w + sws_box_off(n, n_geom, n_tx));
     unsigned long long* pmask = masks ? (unsigned long long*)(w + sws_box_off(n, n_geom, n_tx)) : nullptr;
     // 1. grid trace with z_f = z_land for every ray (+ which elements each pair of consecutive rays brackets)
@@ -606,7 +808,7 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     // three lanes per bracket): 32 element lanes per workgroup, so that its brackets x 3 lanes fit ONE trip of its four waves (84
     // brackets) even where most elements have two or three — a workgroup that needs a second trip doubles the kernel's critical
     // path (measured with 64 element lanes: the first evaluation of the slowest waves started 31 us into a 43 us kernel)
-    const bool trio = (long long)n_geom * n_tx * n_rx <= 32768 && !(flags & RTUS_SOLVE_ONE_LANE);   // (either bracket-finding path)
+    const bool trio = rows * n_rx <= 32768 && !(flags & RTUS_SOLVE_ONE_LANE);   // (either bracket-finding path)
     const long long epb = (trio && masks) ? RTUS_SOLVE_TPB / 8 : (half ? RTUS_SOLVE_TPB / 2 : RTUS_SOLVE_TPB);
     const long long blocks = masks ? (q.n_tasks + epb - 1) / epb : (q.n_tasks + RTUS_SOLVE_WAVES - 1) / RTUS_SOLVE_WAVES;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;

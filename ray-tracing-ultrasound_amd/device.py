@@ -100,7 +100,7 @@ class SolvePlan:
     [G, T, E, 4] and n_roots [G, T, E]."""
 
     def __init__(self, n_geom, n_tx, n_rays, n_rx, *, params: Params = None, fast=False, true_tangent=False,
-                 analytic_lens=False, all_roots=False, device="cuda", one_lane=False):
+                 analytic_lens=False, all_roots=False, device="cuda", one_lane=False, three_launches=False):
         self.p = _resolve(params)
         self.G, self.T, self.N, self.E = int(n_geom), int(n_tx), int(n_rays), int(n_rx)
         self.ws_bytes = int(_lib.lib().rtus_solve_workspace_bytes(self.N, self.G, self.T, self.E))
@@ -112,7 +112,7 @@ class SolvePlan:
             self.out.update(tt_all=torch.empty((G, T, E, 4), **f64), alpha_all=torch.empty((G, T, E, 4), **f64),
                             n_roots=torch.empty((G, T, E), dtype=torch.uint8, device=device))
         self.lens = self.p.lens()
-        self.flags = (1 if fast else 0) | (2 if true_tangent else 0) | (4 if analytic_lens else 0) | (0x10 if one_lane else 0)
+        self.flags = (1 if fast else 0) | (2 if true_tangent else 0) | (4 if analytic_lens else 0) | (0x10 if one_lane else 0) | (0x20 if three_launches else 0)
 
     def run(self, geoms, x_a, z_a, alpha, x_rx, z_land=None, polyline_ready=False):
         """polyline_ready: the previous ``run`` of this plan used the same ``alpha`` tensor contents (RTUS_POLYLINE_READY: the

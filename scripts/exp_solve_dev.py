@@ -13,10 +13,13 @@ cases = {
     "sweep": (np.array([[r * 1e-2, o * 1e-3] for r in range(1, 11) for o in range(-10, 11)]), np.array([0.0])),
     "scale": (np.array([[0.02 + 0.005 * i, 0.0004 * (i - 7.5)] for i in range(16)]), (np.arange(1024) - 511.5) * 0.3e-4),
 }
-for fast in (False, True):
+MODES = [m for m in sys.argv[1:]] or ["default"]
+for fast, mode in [(f, m) for f in (False, True) for m in MODES]:
     for name, (geoms, xa) in cases.items():
         G, T = len(geoms), len(xa)
-        plan = dev_api.SolvePlan(G, T, n, 65, params=rtus.Params(), fast=fast, all_roots=True)
+        plan = dev_api.SolvePlan(G, T, n, 65, params=rtus.Params(), fast=fast, all_roots=True, one_lane=mode == "one_lane",
+                                 three_launches=mode == "three_launches")
+        name = f"{name}/{mode}"
         a = (t64(geoms), t64(xa), t64(np.full(T, d)), alpha, x_rx)
         for _ in range(3):
             o = plan.run(*a)
