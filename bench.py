@@ -1033,7 +1033,10 @@ def solve_measurements(dev_api, rtus, t64, torch):
                   "us_per_pass_polyline_kept": round(msk * 1e3, 2), "M_element_solves_per_s_polyline_kept": round(el / msk / 1e3, 1),
                   "elements_with_a_ray_path": nroot,
                   "roofline": {"bound": "hbm", "binds": "launch floor + the fp64 dependent chain of a traced ray (few waves per SIMD)" if kind == "solve_sweep"
-                               else "valu_issue (grid trace 2/3, refinement 1/3)", "kernel": "rtus_shoot_kernel<%s, true> + rtus_solve_kernel<%s, true>" % (("true",) * 2 if fast else ("false",) * 2),
+                               else "valu_issue (grid trace 2/3, refinement 1/3)",
+                               "kernel": ("rtus_geom1_kernel + rtus_solve_row_kernel<%s> (one launch per pass after the polyline's: a workgroup per row, "
+                                          "three lanes per bracket)" % ("true" if fast else "false")) if kind == "solve_sweep" else
+                                         "rtus_shoot_kernel<%s, true> + rtus_solve_kernel<%s, true>" % (("true",) * 2 if fast else ("false",) * 2),
                                "algorithmic_bytes_per_pass": algb, "achieved": round(algb / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(algb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
             key = kind + ("_fastmath" if fast else "")
@@ -1048,6 +1051,16 @@ def solve_measurements(dev_api, rtus, t64, torch):
                     v["fp64_TFLOP_per_s"] = round(v["fp64_flop_per_pass"] / (ms * 1e-3) / 1e12, 2)
                     v["frac_of_fp64_vector_peak"] = round(v["fp64_flop_per_pass"] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4)
                 e2["roofline_valu"] = v
+            if kind == "solve_sweep":                      # the same pass as separate launches and with the one-lane iteration (round 3's path)
+                for label, kw in (("three_launches", {"three_launches": True}), ("one_lane_three_launches", {"one_lane": True})):
+                    p2 = dev_api.SolvePlan(G, T, N, E, params=rtus.Params(), fast=fast, **kw)
+                    for _ in range(3):
+                        p2.run(*a)
+                    torch.cuda.synchronize()
+                    t2 = Timed(torch, lambda s: p2.run(*a), K)
+                    _, ms2 = t2.run(lambda: None)
+                    e2["us_per_pass_" + label] = round(ms2 * 1e3, 2)
+                    del p2, t2
             entry["vector_form" if fast else "reference_arithmetic"] = e2
             del plan, timed, timed_keep
         entry["note"] = ("polyline_kept: RTUS_POLYLINE_READY — the lens polyline of the alpha grid stays in the workspace between passes "

@@ -37,8 +37,8 @@
 // decisions on all of them.
 #ifdef RTUS_EXP_TIMING   // experiment builds only (scripts/exp_solve_timing.py): wall-clock stamps (100 MHz) per phase and wave
 __device__ unsigned long long rtus_solve_stamps[4096][16];
-#define STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x * RTUS_SOLVE_WAVES + (threadIdx.x >> 6) < 4096) \
-    rtus_solve_stamps[blockIdx.x * RTUS_SOLVE_WAVES + (threadIdx.x >> 6)][i] = wall_clock64(); } while (0)
+#define STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 4096) \
+    rtus_solve_stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)][i] = wall_clock64(); } while (0)
 extern "C" int rtus_solve_stamps_read(unsigned long long* out)
 {
     (void)hipDeviceSynchronize();
@@ -606,6 +606,7 @@ __global__ __launch_bounds__(RTUS_ROW_TPB) void rtus_solve_row_kernel(SolveArgs 
     RayIn in0;
     in0.r_outer = a.geoms[2 * g]; in0.off = a.geoms[2 * g + 1];
     in0.xa = a.x_a[tx]; in0.za = a.z_a[tx]; in0.zf = q.z_land;
+    STAMP(0);
 
     // ---- the grid trace: thread r = ray r (threads past the grid redo its last ray, so that waves stay whole) ----------------------
     {
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(RTUS_ROW_TPB) void rtus_solve_row_kernel(SolveArgs 
             mask_s[wv][c0 + lane] = mine;
         }
     }
+    STAMP(1);
     __syncthreads();
 
     // ---- A: the element lanes (threads 0 .. n_rx - 1) take their brackets from the masks, in ascending alpha -------------------
@@ -701,6 +703,7 @@ __global__ __launch_bounds__(RTUS_ROW_TPB) void rtus_solve_row_kernel(SolveArgs 
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- C: three lanes per bracket, 21 brackets per wave and trip ------------------------------------------------------------------
     for (int i0 = wv * RTUS_TRIO_PER_WAVE; i0 < total; i0 += RTUS_ROW_WAVES * RTUS_TRIO_PER_WAVE) {   // wave-uniform
@@ -715,7 +718,9 @@ __global__ __launch_bounds__(RTUS_ROW_TPB) void rtus_solve_row_kernel(SolveArgs 
         trio_refine<FAST>(q, a, k, land_s, in0, xr, br, n, lane, jb, role, tri[wv], root, T_fin, x_fin);
         if (mine && root) { res_t[slot] = T_fin; res_a[slot] = x_fin; }
     }
+    STAMP(13);
     __syncthreads();
+    STAMP(14);
 
     // ---- D: the element lanes collect their roots (ascending alpha, compacted) ------------------------------------------------------
     if (!live) return;

@@ -22,7 +22,7 @@ assert L.rtus_solve_stamps_read(buf.ctypes.data) == 0
 nw = int((buf[:, 0] > 0).sum())
 s = buf[:nw].astype(np.int64)
 t0 = s[:, 0].min()
-names = ["entry", "A done", "B done"] + [f"eval {i}" for i in range(10)] + ["C done", "barrier", "end"]
+names = ["entry", "A done (row kernel: trace done)", "B done"] + [f"eval {i}" for i in range(10)] + ["C done", "barrier", "end"]
 print("wave-level stamps, microseconds after the first wave's entry (100 MHz clock); waves that skip a phase keep 0")
 for i, nm in enumerate(names):
     v = s[:, i]; ok = v > 0

@@ -265,7 +265,7 @@ for size in ("sweep", "scale"):
         tot_valu = fl = 0.0
         clk = 2.1
         for k, c in t.items():
-            short = "grid_trace" if "shoot" in k else "refine"
+            short = "grid_trace" if "shoot" in k else ("grid_trace_and_refine_one_launch" if "row_kernel" in k else "refine")
             w = c["SQ_WAVES"]
             per[short] = {"kernel": k, "waves": int(w), "insts_valu_per_wave": round(c["SQ_INSTS_VALU"] / w, 1),
                           "insts_salu_per_wave": round(c["SQ_INSTS_SALU"] / w, 1), "insts_smem_per_wave": round(c.get("SQ_INSTS_SMEM", 0) / w, 1),
