@@ -96,3 +96,35 @@ def test_one_launch_three_launches_and_one_lane(rtus):
     assert (fast1[4] == fast3[4]).mean() > 0.999
     mf = (fast1[4] == fast3[4])[..., None] & np.isfinite(fast1[2]) & np.isfinite(fast3[2])
     assert np.max(np.abs(fast1[2] - fast3[2])[mf]) < 1e-13
+
+
+@pytest.mark.parametrize("n,n_rx", [(70, 1), (1000, 64), (1024, 128), (905, 65), (129, 127)])
+def test_one_launch_path_ragged_sizes(rtus, n, n_rx):
+    """The one-launch kernel at the edges of its domain (grid of up to 1,024 rays = one workgroup, up to 128 elements, the last 64-ray
+    block partly filled, a single element, an unsorted aperture with a duplicate and a NaN): the same bits as the separate launches,
+    the same roots as the oracle's bisection."""
+    from oracle import cport
+    rng = np.random.default_rng(n * 131 + n_rx)
+    alpha = np.linspace(-rtus.ALPHA_MAX, rtus.ALPHA_MAX, n)
+    x = rng.uniform(-0.019, 0.019, n_rx)
+    if n_rx > 4:
+        x[3] = x[1]
+        x[2] = np.nan
+    geoms = np.array([[0.037, 0.0038], [0.02, -0.006], [0.08, 0.001]])
+    txs = np.array([0.0021, -0.011])
+    za = np.full(2, D_PLANE)
+    one = rtus.solve_travel_times(txs, za, x, alpha, geoms, params=rtus.Params(), all_roots=True)
+    three = rtus.solve_travel_times(txs, za, x, alpha, geoms, params=rtus.Params(), all_roots=True, three_launches=True)
+    for a, b in zip(one, three):
+        assert np.array_equal(a, b, equal_nan=True)
+    if n_rx > 4:
+        assert one[4][:, :, 2].max() == 0 and np.isnan(one[0][:, :, 2]).all()          # the NaN element has no ray path
+        assert np.array_equal(one[2][:, :, 1], one[2][:, :, 3], equal_nan=True)         # duplicates: the same roots
+    ok = np.isfinite(x)
+    for g in range(3):
+        for t in range(2):
+            otm, ota, oaa = cport.solve(txs[t], D_PLANE, D_PLANE, alpha, x[ok], geoms[g, 0], geoms[g, 1])
+            same = np.isfinite(ota).sum(1) == one[4][g, t][ok]
+            assert same.mean() > 0.9 or n < 100
+            m = same[:, None] & np.isfinite(ota)
+            assert np.max(np.abs(one[2][g, t][ok] - ota)[m], initial=0) < 1e-13
