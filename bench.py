@@ -442,6 +442,8 @@ def main(argv=None):
             "workload": ("REHEARSAL SIZES (RTUS_BENCH_SMALL=1), not a measurement — " if SMALL else "") + DESCR[wl] + ("" if world == 1 else
                                      f"; {scaling}-scaled over {world} GPUs" +
                                      (f" ({units_per_step // n_f if m is not None else 0} tx rows per GPU)" if m is not None else "")),
+            "tier": ("RTUS_TT_TAUP_TAIL (rtus_tt_layers_ex*, taup=True; <= 6e-11 relative)" if args.tier == "taup" else
+                     "default (flags = 0; <= 1e-13 relative)") if wl in PLANAR else "n/a",
             "solves_per_step_per_gpu": units_per_step,
             "solves_per_step_all_gpus": total_units_per_step,
             "numerics": {"cfg4_lens_f32": "fp32 throughout (|dt| < 2e-10 s vs fp64 where both follow the same ray path; DESIGN section 4 on minima at the end of the search interval)"}.get(
