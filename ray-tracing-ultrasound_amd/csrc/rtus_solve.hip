@@ -116,7 +116,11 @@ __device__ __forceinline__ void trio_refine(const SolveArgs& q, const ShootArgs&
         xt = q.alpha[ok1 ? c1 : c2];
         ft = (ok1 ? l1 : (ok2 ? l2 : NAN)) - xr;
     }
-    const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
+    // one evaluation at a grid ray: it IS the root (fhi == 0), both ends are within 1e-13 m (x_land flat to rounding), or ONE end is
+    // within 1e-15 m — a root at a grid ray up to rounding, where a triple around the candidate would have no width (the centre
+    // element over a centred or mirror-symmetric pipe: x_land(0) = x_e to ~1e-17 m)
+    const bool end_hi = fabs(fhi) <= 1e-15, end_lo = fabs(flo) <= 1e-15;
+    const bool single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13) || end_hi || end_lo;
     const double sec = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
     double cand = solve_iqi(xlo, flo, xhi, fhi, xt, ft);             // NaN without a third ray
     if (!(cand > xlo && cand < xhi)) cand = sec;

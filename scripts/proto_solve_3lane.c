@@ -52,7 +52,7 @@ static int three(Ctx *c, const double *alpha, const double *land, int br, int n,
     double xt = NAN, ft = NAN;
     if (t1 >= 0 && t1 < n && isfinite(land[t1])) { xt = alpha[t1]; ft = land[t1] - c->xe; }
     else if (t2 >= 0 && t2 < n && isfinite(land[t2])) { xt = alpha[t2]; ft = land[t2] - c->xe; }
-    const int single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13);
+    const int single = fhi == 0.0 || (fabs(flo) <= 1e-13 && fabs(fhi) <= 1e-13) || fabs(fhi) <= 1e-15 || fabs(flo) <= 1e-15;
     double cand = iqi(xlo, flo, xhi, fhi, xt, ft);
     const double sec = xlo - flo * (xhi - xlo) / (fhi - flo);
     if (!(cand > xlo && cand < xhi)) cand = sec;
