@@ -244,7 +244,10 @@ int rtus_ray_hits(const double *land_x, int n_batch, int n_rays, const double *x
  *   geoms, x_a, z_a, alpha, z_f, flags   as rtus_shoot*
  *   x_rx [n_rx], atol, rtol               as rtus_match*   (any n_rx; rows * (n_rx rounded up to 64) < 2^31)
  *   first_ray / hit / tof_hit [n_geom*n_tx][n_rx]   as rtus_match*   (hit, tof_hit nullable)
- *   tof, land_x [n_geom*n_tx][n_rays]     nullable: the per-ray arrays, stored only when asked for
+ *   tof, land_x [n_geom*n_tx][n_rays]     nullable: the per-ray arrays, stored only when asked for.  Without `tof` (what the
+ *                                         reference's loop needs: main_rt.py:497-500 sums the segments of the HIT ray only) the
+ *                                         four segment times are worked out only in waves that matched an element: 8 % less
+ *                                         time at 8 M rays, the same tof_hit bits
  *   workspace  rtus_sweep_workspace_bytes(n_rays, n_geom, n_tx, n_rx) bytes, 64-byte aligned.
  *              RTUS_POLYLINE_READY here means: the previous call on this workspace was rtus_sweep_dev
  *              with the same alpha, n_rays, n_geom, n_tx and n_rx (the lens polyline is kept AND the

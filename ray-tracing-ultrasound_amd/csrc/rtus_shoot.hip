@@ -260,7 +260,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
     }
     if (a.land_x) a.land_x[row * n + r] = x_in;
     if (a.status) a.status[row * n + r] = isnan(xq) ? RTUS_RAY_REF_RAISES : 0;
-    if (a.tof4 || a.tof) {
+    if (a.tof4 || (a.tof && !(MATCH && a.tof_lazy))) {
         const double t1 = seg_time<FAST>(xa, za, P.x, P.y, k.c1, k.inv_c1);   // main_compare.py:514
         const double t2 = seg_time<FAST>(P.x, P.y, xq, zq, k.c2, k.inv_c2);   // :515
         const double t3 = seg_time<FAST>(xq, zq, xi, zi, k.c2, k.inv_c2);     // :516
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { wlo = fmin(wlo, __shfl_xor(wlo, o)); whi = fmax(whi, __shfl_xor(whi, o)); }
         int32_t* __restrict__ mrow = a.m_first + row * (size_t)a.rx_pad;
+        lanemask any_cand = 0;                                          // (wave-uniform) some element's first matching ray so far is in this wave
         for (int c0 = 0; c0 < a.rx_pad; c0 += 64) {
             const bool ev = c0 + lane < a.n_rx;
             const double xv = a.x_rx[min(c0 + lane, a.n_rx - 1)];
@@ -307,6 +308,17 @@ __global__ __launch_bounds__(RTUS_BLOCK) __attribute__((amdgpu_waves_per_eu(RTUS
                 cand = (lane == e && m) ? first : cand;
             }
             if (cand != RTUS_NO_RAY) atomicMin(&mrow[c0 + lane], cand);
+            any_cand |= __ballot(cand != RTUS_NO_RAY);
+        }
+        // The caller wants the hits only (no per-ray travel times): the finalize kernel reads the time of an element's WINNING ray,
+        // and a winner lies in a wave that matched something — every other wave (nearly all: a ray within 1e-6 m of an element is
+        // rare) skips the four segment times, ~135 of its ~950 VALU instructions.  The same arithmetic in the same wave: the same bits.
+        if (a.tof_lazy && any_cand && live) {
+            const double t1 = seg_time<FAST>(xa, za, P.x, P.y, k.c1, k.inv_c1);
+            const double t2 = seg_time<FAST>(P.x, P.y, xq, zq, k.c2, k.inv_c2);
+            const double t3 = seg_time<FAST>(xq, zq, xi, zi, k.c2, k.inv_c2);
+            const double t4 = seg_time<FAST>(xi, zi, x_in, zf, k.c1, k.inv_c1);
+            a.tof[row * n + r] = ((t1 + t2) + t3) + t4;                 // main_rt.py:497-500
         }
         // (rtus_sweep_finalize_kernel turns the winners into first_ray / hit / tof_hit.  Finalizing inside this kernel — the last
         // wave of a row to arrive, counted by an atomic — was built and measured: no faster for the reference's sweep (29.7 us
@@ -353,6 +365,7 @@ hipError_t rtus_launch_shoot_ex(const rtus_lens& lens, const double* geoms, int 
     if ((unsigned long long)a.n_tree * sizeof(TreeNode) >= 0xffffffffull) return hipErrorInvalidValue;   // the walk's record offsets are 32-bit
     a.out8 = out8; a.tof4 = tof4; a.tof = tof; a.land_x = land_x; a.status = status;
     a.n_tx = n_tx; a.n_geom = n_geom;
+    a.tof_lazy = 0;
     a.flags = flags;
     if (!(flags & RTUS_POLYLINE_READY)) rtus_launch_geometry(a, alpha, s);
     const dim3 grid((n + RTUS_BLOCK - 1) / RTUS_BLOCK, n_tx, n_geom);
@@ -423,6 +436,7 @@ hipError_t rtus_launch_sweep(const rtus_lens& lens, const double* geoms, int n_g
     a.atol = atol; a.rtol = rtol;
     a.out8 = nullptr; a.tof4 = nullptr; a.land_x = land_x; a.status = nullptr;
     a.tof = tof ? tof : (double*)(w + sweep_al(shoot_ws_bytes(n)) + sweep_al(4 * rows * rx_pad));
+    a.tof_lazy = tof ? 0 : 1;                                           // hits only: times of the waves that matched something
     a.n_tx = n_tx; a.n_geom = n_geom; a.flags = flags;
     if (!(flags & RTUS_POLYLINE_READY)) {
         // the matcher's scratch starts idle: inside the polyline kernel when that costs it at most 64 stores per thread, by a fill

@@ -782,7 +782,7 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
         a.k = make_lens_k(lens);
         a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = nullptr; a.zf_const = z_land;
         shoot_args_workspace(a, w, n);
-        a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0;
+        a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0; a.tof_lazy = 0;
         a.n_tx = n_tx; a.n_geom = n_geom; a.flags = flags;
         if (!(flags & RTUS_POLYLINE_READY)) rtus_launch_geometry_only(a, alpha, s);
         q.alpha = alpha; q.land_x = nullptr; q.land_box = nullptr; q.pair_mask = nullptr; q.rx_pad = (n_rx + 63) & ~63; q.nb = (n + 63) / 64; q.x_rx = x_rx;
@@ -804,7 +804,7 @@ hipError_t rtus_launch_solve(const rtus_lens& lens, const double* geoms, int n_g
     a.k = make_lens_k(lens);
     a.geoms = geoms; a.x_a = x_a; a.z_a = z_a; a.z_f = nullptr; a.zf_const = z_land;
     shoot_args_workspace(a, w, n);
-    a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0;
+    a.out8 = nullptr; a.tof4 = nullptr; a.tof = nullptr; a.land_x = nullptr; a.status = nullptr; a.land_box = nullptr; a.pair_mask = nullptr; a.x_rx = nullptr; a.n_rx = 0; a.rx_pad = 0; a.tof_lazy = 0;
     a.n_tx = n_tx; a.n_geom = n_geom;
     a.flags = flags;
     q.alpha = alpha; q.land_x = land; q.land_box = boxes; q.pair_mask = pmask; q.rx_pad = (n_rx + 63) & ~63; q.nb = (n + 63) / 64; q.x_rx = x_rx; q.z_land = z_land; q.n_rx = n_rx;

@@ -54,6 +54,7 @@ struct ShootArgs {
     // the fused sweep (rtus_shoot_kernel<., ., true>): the element matcher of main_rt.py:487-501 asked while the landing points are in registers
     int32_t* __restrict__ m_first;      // scratch [rows][rx_pad]: smallest matching ray index so far, RTUS_NO_RAY when idle
     double atol, rtol;
+    int tof_lazy;                       // fused sweep without a per-ray `tof` output: only waves that matched an element work out their rays' times
     double zf_const;
     int n, n_tx, n_geom, n0, n1, n2, n3, n_tree;    // n3: 4096-point boxes, only when n2 > 8 (else 0); they live in the tree only
     unsigned flags;
