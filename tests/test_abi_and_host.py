@@ -176,3 +176,21 @@ def test_kernel_resources_of_the_trace_kernels():
         assert v[".private_segment_fixed_size:"] == 0 and v[".vgpr_spill_count:"] == 0 and v[".vgpr_count:"] <= 80, (k, v)
     for k, v in solve.items():
         assert v[".vgpr_count:"] <= 128 and v[".private_segment_fixed_size:"] <= 32, (k, v)
+
+
+def test_python_flag_constants_are_the_headers():
+    """The Python layer repeats a few flag values of include/rtus.h (no header parsing at import time): they must be the header's."""
+    import re
+    import rtus
+    from importlib import import_module
+    api = import_module("ray-tracing-ultrasound_amd.api")
+    hdr = open(os.path.join(ROOT, "include", "rtus.h")).read()
+    val = lambda name: int(re.search(r"#define\s+%s\s+(0x[0-9a-fA-F]+)u" % name, hdr).group(1), 16)
+    assert api.TAUP_TAIL == val("RTUS_TT_TAUP_TAIL")
+    assert api.SOLVE_ONE_LANE == val("RTUS_SOLVE_ONE_LANE") and api.SOLVE_THREE_LAUNCHES == val("RTUS_SOLVE_THREE_LAUNCHES")
+    assert api.SHOOT_FAST_MATH == val("RTUS_SHOOT_FAST_MATH") and api.TRUE_PIPE_TANGENT == val("RTUS_TRUE_PIPE_TANGENT")
+    assert api.ANALYTIC_LENS == val("RTUS_ANALYTIC_LENS")
+    # argument errors of the new keywords are raised before any library call (no GPU needed)
+    import numpy as np
+    with pytest.raises(ValueError):
+        rtus.travel_time_layers([0.02], [2330.0, 1483.0], [0.0], [0.0], [0.0], [0.03], taup=True, return_iters=True)
