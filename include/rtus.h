@@ -351,6 +351,12 @@ int rtus_tt_layers_sorted_dev(const double *z_if, const double *c, int n_if,
  *   alpha_lo/hi    search interval for the refraction point's polar angle (e.g. -/+ alpha_max, main_rt.py:457)
  *   xe,ze [n_e]    elements;  xf,zf [n_f]  targets
  *   tt [n_e][n_f]  travel times;  alpha_out [n_e][n_f] nullable: polar angle of the refraction point
+ * The entry is the LEAST time over [alpha_lo, alpha_hi] (Fermat).  The lens is aplanatic: around its focus T(alpha) is nearly flat
+ * and has two local minima (an interior ray and an end of the interval, or both ends beyond the focus); the kernel follows one
+ * minimum from element to element and looks at the whole interval wherever a second one can exist — a target pinned at an end, or
+ * d2T/dalpha2 at the minimum below 0.125 h0 / c2 (7.5e-6 s/rad^2 for the reference lens: twice the largest value measured at an
+ * interior minimum of a pair with two minima, scripts/study_lens_minima.py).  That threshold is CALIBRATED ON THE REFERENCE LENS
+ * (main_rt.py:449-457) and scaled with the lens's own time h0 / c2; for another lens design check it with the same study.
  * ---------------------------------------------------------------------------------------- */
 int rtus_tt_lens_dev(const rtus_lens *lens, double alpha_lo, double alpha_hi,
                      const double *d_xe, const double *d_ze, int n_e,
