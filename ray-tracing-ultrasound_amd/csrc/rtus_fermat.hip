@@ -521,9 +521,6 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
 #else
     const dim3 grid(a.gx, a.gy, n_batch), block(RTUS_BLOCK);
 #endif
-#ifdef RTUS_EXP_TAUP_DEFAULT                                // experiment builds only (scripts/ab_planar.py)
-    flags |= RTUS_TT_TAUP_TAIL;
-#endif
     const bool taup = (flags & RTUS_TT_TAUP_TAIL) != 0;
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, 0, s, a); \

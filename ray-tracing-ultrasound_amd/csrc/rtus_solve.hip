@@ -217,10 +217,8 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
     __shared__ int item_r[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
     __shared__ double res_t[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS], res_a[RTUS_SOLVE_TPB * RTUS_MAX_ROOTS];
     __shared__ int wave_tot[RTUS_SOLVE_WAVES];
-#ifndef RTUS_SOLVE_NO_RESCUE
     __shared__ double resc_in[RTUS_SOLVE_WAVES][RTUS_RESCUE_MAX][6];      // xa, za, r_outer, pipe_offset, candidate, delta
     __shared__ double resc_out[RTUS_SOLVE_WAVES][RTUS_RESCUE_MAX][2][2];  // [below / above the candidate] = landing x, travel time
-#endif
     const ShootArgs& a = q.s;
     const LensK& k = a.k;
     const int n = a.n;
@@ -441,7 +439,6 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
             bool helper = false, rescued = false;
             int hj = 0, hs = 0, rj = 0;
             double ac = cand;                                            // a finished lane re-traces its last point: same bits, ignored
-#ifndef RTUS_SOLVE_NO_RESCUE
             double delta = 0.0;
             if (it >= 2) {                                               // wave-uniform
                 const lanemask U = __ballot(!done), Dm = __ballot(done);
@@ -469,7 +466,6 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
             }
-#endif
             double sn, cs, px, pz, dz, dx;
             rtus_sincos(ac, sn, cs);                                     // |alpha| < 8: the bounded-range kernels
             lens_eval_sc(k, sn, cs, px, pz, dz, dx);                     // main_rt.py:338, 344 at this lane's alpha
@@ -484,7 +480,6 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
             const double t3 = seg_time<FAST>(o.xq, o.zq, o.xi, o.zi, k.c2, k.inv_c2);
             const double t4 = seg_time<FAST>(o.xi, o.zi, o.x_in, q.z_land, k.c1, k.inv_c1);
             const double T = ((t1 + t2) + t3) + t4;
-#ifndef RTUS_SOLVE_NO_RESCUE
             if (it >= 2) {                                               // wave-uniform
                 if (helper) { resc_out[wv][hj][hs][0] = o.x_in; resc_out[wv][hj][hs][1] = T; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -507,7 +502,6 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
                     } else if (fc == 0.0) { ++nev; done = true; f_fin = 0.0; x_fin = ac; T_fin = T; }
                 }
             }
-#endif
             if (!done) {
                 ++nev;
                 if (!isfinite(fc)) { dead = true; done = true; }         // the branch ends inside the bracket
