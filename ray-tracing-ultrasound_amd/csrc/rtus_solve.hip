@@ -166,12 +166,20 @@ __device__ __forceinline__ void trio_refine(const SolveArgs& q, const ShootArgs&
                 if (mono) {
                     x3 = solve_iqi(cand, f0, cand - delta, fm, cand + delta, fq);
                     const double u = (x3 - cand) * solve_rcp(delta);
-                    if (delta <= 1e-8 && fabs(u) <= 8.0) {       // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad)
+                    // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad.)  And the branch must be CONTINUOUS across the
+                    // triple — x_land also changes sign at jumps (the first crossing moves to another chord: every element between the two
+                    // landing points is "bracketed"), and a jump is no ray path: a slope beyond 1e3 m/rad over 2e-8 rad is one
+                    // (found by scripts/fuzz_solve.py: whole rows reported an extra root; the reference's own sweep has no jump)
+                    if (delta <= 1e-8 && fabs(u) <= 8.0 && fabs(fq - fm) <= 2e3 * delta) {
                         done = true;
                         f_fin = 0.0;                                 // a root next to three fresh points
                         x_fin = x3;
                         T_fin = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm)));
                     }
+                }
+                // a jump: the sign changes across a triple 2e-8 rad wide by more than a continuous branch's could (> 5e3 m/rad): no root
+                if (!done && delta > 0.0 && delta <= 1e-8 && isfinite(fm) && isfinite(fq) && (fm < 0.0) != (fq < 0.0) && fabs(fq - fm) > 1e-4) {
+                    dead = true; done = true;
                 }
                 if (!done) {
                     // the three points tighten the bracket; the next centre comes from them

@@ -74,8 +74,9 @@ static int three(Ctx *c, const double *alpha, const double *land, int br, int n,
         if (mono && d > 0) {
             x3 = iqi(cand, f0, cand - d, fm, cand + d, fq);
             const double u = (x3 - cand) / d;
-            if ((d <= DACC && fabs(u) <= UMAX) || (rd >= 2 && fabs(f0) <= 1e-9 && fabs(x3 - cand) <= 1e-8)) { *root = x3; *Tr = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm))); return 1; }
+            if (d <= DACC && fabs(u) <= UMAX && fabs(fq - fm) <= 2e3 * d) {          /* ... and continuous across the triple: a jump is no root */ *root = x3; *Tr = T0 + 0.5 * u * ((Tq - Tm) + u * ((Tq - T0) - (T0 - Tm))); return 1; }
         }
+        if (d > 0 && d <= DACC && fin3 && (fm < 0) != (fq < 0) && fabs(fq - fm) > 1e-4) return 0;     /* a jump across 2e-8 rad: no root */
         const double xs[3] = {cand - d, cand, cand + d}, fs[3] = {fm, f0, fq};
         for (int i = 0; i < 3; ++i) { if (!isfinite(fs[i])) continue; if ((fs[i] < 0) == (flo < 0)) { if (xs[i] > xlo) { xlo = xs[i]; flo = fs[i]; } } else if (xs[i] < xhi) { xhi = xs[i]; fhi = fs[i]; } }
         if (xhi - xlo <= 1e-13) { *root = cand; *Tr = T0; return fabs(f0) < 1e-9; }  /* a jump, or the root itself */

@@ -50,3 +50,15 @@ def test_fuzz_lens_kernels_vs_oracle(rtus):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK: 25 trials" in r.stdout
+
+
+def test_fuzz_root_finding_solve_vs_oracle(rtus):
+    """scripts/fuzz_solve.py: rtus_solve in its three forms (one launch / three launches with three lanes per bracket, one lane per
+    bracket) against the oracle's bisection on random geometries (centred and near-tangent pipes too), transmit points, apertures and
+    grids; 45 trials here (long run: profiles/README.md).  Root counts equal except where a branch ends inside a bracket (<= 1 % of
+    the elements), roots within 1e-13 s / 1e-11 rad.  (It found round 4's first three-lane acceptance rule reporting a root at every
+    JUMP of x_land — a sign change across a discontinuity — for whole rows of near-tangent geometries: the triple must be continuous.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_solve.py"), "45", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK: 45 trials" in r.stdout
