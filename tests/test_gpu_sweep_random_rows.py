@@ -25,11 +25,12 @@ def _oracle_decisions(cport, xa, za, zf, alpha, geoms, xe, atol):
     G, T = o8.shape[:2]
     hit = np.zeros((G, T, xe.size), dtype=bool)
     first = np.zeros((G, T, xe.size), dtype=np.int32)
+    tof = np.zeros((G, T, xe.size))
     for g in range(G):
         for t in range(T):
-            h, _, f = cport.match(o8[g, t, 6], cport.tof4(xa[t], za[t], o8[g, t]), xe, atol)
-            hit[g, t], first[g, t] = h, np.where(h, f, -1)
-    return o8[:, :, 6], hit, first
+            h, tf, f = cport.match(o8[g, t, 6], cport.tof4(xa[t], za[t], o8[g, t]), xe, atol)
+            hit[g, t], first[g, t], tof[g, t] = h, np.where(h, f, -1), tf
+    return o8[:, :, 6], hit, first, tof
 
 
 def test_hit_flags_on_2100_random_rows(rtus):
@@ -47,7 +48,7 @@ def test_hit_flags_on_2100_random_rows(rtus):
     xe = rtus.reference_elements()
     got = rtus.sweep_batch(xa, za, zf, alpha, xe, geoms=geoms, params=rtus.Params(), atol=atol, want=("land_x",))
     g_hit, g_first = got["hit"], np.where(got["hit"], got["first_ray"], -1)
-    land, o_hit, o_first = _oracle_decisions(cport, xa, za, zf, alpha, geoms, xe, atol)
+    land, o_hit, o_first, o_tof = _oracle_decisions(cport, xa, za, zf, alpha, geoms, xe, atol)
     assert o_hit.shape == g_hit.shape == (G, T, 65) and G * T >= 2000
     diff = np.argwhere((g_hit != o_hit) | (g_first != o_first))
     # which decisions does the oracle itself keep under last-bit noise of its trigonometry?
@@ -59,7 +60,7 @@ def test_hit_flags_on_2100_random_rows(rtus):
             for mode in NOISE_MODES + [int(v) for v in np.random.default_rng(5).integers(1, 2 ** 32, 4)]:
                 cport.set_trig_noise(mode)
                 for g, t in rows:
-                    _, h, f = _oracle_decisions(cport, xa[t:t + 1], za[t:t + 1], zf, alpha, geoms[g:g + 1], xe, atol)
+                    _, h, f, _tf = _oracle_decisions(cport, xa[t:t + 1], za[t:t + 1], zf, alpha, geoms[g:g + 1], xe, atol)
                     kept_hit[g, t] &= h[0, 0] == o_hit[g, t]
                     kept_first[g, t] &= f[0, 0] == o_first[g, t]
         finally:
@@ -80,4 +81,7 @@ def test_hit_flags_on_2100_random_rows(rtus):
     print(f"{G * T} rows x 65 elements: {n_hits} oracle hits, {len(diff)} (row, element) decisions differ, {len(hard)} of them on decisions the "
           f"oracle keeps under last-bit perturbations of its own trigonometry")
     assert n_hits > 1500                                                   # the comparison is about something
+    # the travel time of every agreed hit (hits-only call: the trace kernel works out segment times only in waves that matched something)
+    agree = g_hit & o_hit & (g_first == o_first)
+    assert np.max(np.abs(got["tof_hit"] - o_tof)[agree]) < 1e-15 and np.all(got["tof_hit"][~g_hit] == 0.0)
     assert not hard, hard[:10]
