@@ -166,11 +166,12 @@ __device__ __forceinline__ void trio_refine(const SolveArgs& q, const ShootArgs&
                 if (mono) {
                     x3 = solve_iqi(cand, f0, cand - delta, fm, cand + delta, fq);
                     const double u = (x3 - cand) * solve_rcp(delta);
-                    // (up to 8e-8 rad from the centre: a kink in between costs <= 8e-12 rad.)  And the branch must be CONTINUOUS across the
+                    // (within 2 d of the centre: a kink in between costs <= 2 d x the slope's jump — 1e-4 relative on the reference's 905-point
+                    // polyline, ~1e-3 on a 120-point one: <= 6e-12 rad at d = 3e-9.)  And the branch must be CONTINUOUS across the
                     // triple — x_land also changes sign at jumps (the first crossing moves to another chord: every element between the two
                     // landing points is "bracketed"), and a jump is no ray path: a slope beyond 1e3 m/rad over 2e-8 rad is one
                     // (found by scripts/fuzz_solve.py: whole rows reported an extra root; the reference's own sweep has no jump)
-                    if (delta <= 1e-8 && fabs(u) <= 8.0 && fabs(fq - fm) <= 2e3 * delta) {
+                    if (delta <= 1e-8 && fabs(u) <= 2.0 && fabs(fq - fm) <= 2e3 * delta) {
                         done = true;
                         f_fin = 0.0;                                 // a root next to three fresh points
                         x_fin = x3;
@@ -192,7 +193,7 @@ __device__ __forceinline__ void trio_refine(const SolveArgs& q, const ShootArgs&
                         double nc = x3;
                         if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) * solve_rcp(fhi - flo);
                         if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev_abs) { nc = 0.5 * (xlo + xhi); delta = 0.25 * (xhi - xlo); }
-                        else delta = fmax(fmin(fmax(3e-9, fmin(1e-4 * delta, 1e-8)), 0.25 * fabs(nc - cand)), 1e-11);   // (a wide first triple may straddle a kink: its zero is good to ~1e-4 d)
+                        else delta = fmax(fmin(3e-9, 0.25 * fabs(nc - cand)), 1e-11);
                         fprev_abs = fabs(f0);
                         x_fin = cand; T_fin = T0; f_fin = f0;        // (what an exhausted iteration reports)
                         cand = nc;

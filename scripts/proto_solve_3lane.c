@@ -40,7 +40,7 @@ static int bisect(Ctx *c, double a, double fa, double b, double fb, double *root
     fm = F(c, *root, T);
     return fabs(fm) < 1e-9;
 }
-static double DSCALE = 4.0, DMIN = 3e-6, DMAX = 1e-4, DACC = 1e-8, D2 = 3e-9, UMAX = 2.0;
+static double DSCALE = 4.0, DMIN = 3e-6, DMAX = 1e-4, DACC = 1e-8, D2 = 3e-9, UMAX = 2.0;   /* the kernel's values */
 /* the rule the kernel uses (rtus_solve_kernel<., ., ., true>): every round evaluates cand - d, cand, cand + d; the root of the inverse
  * quadratic through the three is ACCEPTED when d <= DACC (x_land has kinks where the return ray moves to the next polyline chord:
  * a wide triple that straddles one is off by d x the slope's jump), otherwise it is the next candidate with d = D2 */
@@ -83,7 +83,7 @@ static int three(Ctx *c, const double *alpha, const double *land, int br, int n,
         double nc = x3;
         if (!(nc > xlo && nc < xhi)) nc = xlo - flo * (xhi - xlo) / (fhi - flo);
         if (!(nc > xlo && nc < xhi) || fabs(f0) > 0.5 * fprev) { nc = 0.5 * (xlo + xhi); d = 0.25 * (xhi - xlo); }
-        else d = fmax(fmin(fmax(D2, fmin(1e-4 * d, DACC)), 0.25 * fabs(nc - cand)), 1e-11);
+        else d = fmax(fmin(D2, 0.25 * fabs(nc - cand)), 1e-11);
         fprev = fabs(f0);
         cand = nc;
     }
