@@ -185,8 +185,8 @@ int rtus_shoot(const rtus_lens *lens, const double *geoms, int n_geom,
  * two rounds of evaluations instead of two or three; such a call leaves most of the chip idle and lasts as long as its slowest
  * bracket), beyond that one lane per bracket.  Against a bisection to the last bit (scripts/fuzz_solve.py, 420 random trials, 82,472
  * roots, identical root counts): three lanes |dt| <= 8e-15 s, |dalpha| <= 1e-11 rad + the traces' own landing noise / slope; one
- * lane — it stops once the landing point is within 1e-9 m and its next step below 1e-8 rad — |dt| <= 2e-12 s, |dalpha| <= 2e-9 rad
- * on steep or kinked stretches of x_land (<= 4e-15 s on the reference's own sweep).  Within one scheme a bracket's bits do not
+ * lane — it stops once the landing point is within 1e-9 m and its next step below 1e-8 rad, and applies that step — |dt| <= 6e-15 s,
+ * |dalpha| <= 5e-11 rad + the same noise term (measured worst 1.9e-11 rad).  Within one scheme a bracket's bits do not
  * depend on the aperture's order or on the other brackets of the call.  RTUS_SOLVE_ONE_LANE asks for the one-lane scheme whatever
  * the size (bits independent of the call's size too). */
 #define RTUS_SOLVE_ONE_LANE 0x10u

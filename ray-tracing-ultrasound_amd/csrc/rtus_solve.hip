@@ -455,7 +455,10 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
                 if (nu <= RTUS_RESCUE_MAX && __popcll(Dm) >= 2 * nu) {
                     const int j = __builtin_amdgcn_mbcnt_hi((unsigned)(U >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)U, 0));
                     const int h = __builtin_amdgcn_mbcnt_hi((unsigned)(Dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Dm, 0));
-                    delta = fmin(0.5 * fabs(cand - xp), 0.999 * fmin(cand - xlo, xhi - cand));
+                    // (round 4: at most 1e-8 rad — x_land has kinks where the returning ray changes chords, and a wide triple that
+                    // straddles one is off by delta x the slope's jump: scripts/fuzz_solve.py measured 1.6e-9 rad / 1.8e-12 s with the
+                    // round-3 rule, half the step that led here, on 120-point polylines; see trio_refine)
+                    delta = fmin(fmin(0.5 * fabs(cand - xp), 1e-8), 0.999 * fmin(cand - xlo, xhi - cand));
                     rescued = !done && delta > 0.0;
                     rj = j;
                     if (!done) {
@@ -497,14 +500,15 @@ __global__ __launch_bounds__(RTUS_SOLVE_TPB) __attribute__((amdgpu_waves_per_eu(
                 if (rescued && isfinite(fc)) {
                     const double fm = resc_out[wv][rj][0][0] - xr, fq = resc_out[wv][rj][1][0] - xr;
                     const double Tm = resc_out[wv][rj][0][1], Tq = resc_out[wv][rj][1][1];
-                    // the root inside the three points (a sign change between the outer two) and x_land monotone over them
-                    if ((fm < 0.0) != (fq < 0.0) && (fq - fc) * (fc - fm) > 0.0 && fc != 0.0) {
+                    // x_land monotone over the three points and (round 4) CONTINUOUS over them: a sign change across a jump of
+                    // x_land is no ray path — see trio_refine
+                    if ((fq - fc) * (fc - fm) > 0.0 && fc != 0.0 && fabs(fq - fm) <= 2e3 * delta) {
                         const double xr3 = solve_iqi(ac, fc, ac - delta, fm, ac + delta, fq);
-                        const double u = (xr3 - ac) * solve_rcp(delta);  // in (-1, 1)
-                        if (fabs(u) < 1.0) {
+                        const double u = (xr3 - ac) * solve_rcp(delta);  // within two delta of the centre, as in trio_refine
+                        if (fabs(u) <= 2.0) {
                             ++nev;
                             done = true;
-                            f_fin = 0.0;                                 // bracketed between fresh points 2 delta apart: a root
+                            f_fin = 0.0;                                 // a root next to three fresh points
                             x_fin = xr3;
                             T_fin = T + 0.5 * u * ((Tq - Tm) + u * ((Tq - T) - (T - Tm)));
                         }
