@@ -86,13 +86,19 @@ struct __attribute__((aligned(16))) ElemRec {
     int row;                // PERM: the element's output row
 };
 
+typedef const __attribute__((address_space(3))) ElemRec* RecPtr;   // a record where it lives: LDS (ds_read at a register + immediate offset)
+
 // Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
 // traversed layer (there k = 0 and w = (1 + k q^2)^(-1/2) = 1 exactly: slot 0 needs no rsqrt anywhere).
+#ifndef RTUS_PLANAR_TAU
+#define RTUS_PLANAR_TAU 3e-4f   // relative size of the Newton step at which a lane stops (and does not take it)
+#endif
 template <int NL>
 struct Lane {
     double hr0, hc0, hr[NL], kk[NL], hc[NL], inv_cm;       // slots 1 .. NL-1 of the arrays are used
     float hr0f, hrf[NL], kkf[NL], rs0f, rhmf, asymf;       // fp32 copies for the Newton loop, cold-start bounds
-    float inv_cmf;                                         // (tau-p tail: scales its second-order term)
+    float hic;                                             // 1 / (2 cm) (tau-p tail: scales its second-order term)
+    float G, dG;                                           // tau-p tail: u^3 / (2 cm X'(q)) of the latest solve + its change per element (see HOLD)
     float tau;                                             // relative step below which a lane stops (+inf: target not below the element)
     float rS3;                                             // 1 / X'(q) of the latest evaluation
 };
@@ -101,7 +107,7 @@ template <int NL>
 __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, double zf, Lane<NL>& L)
 {
     const bool valid = zf > ze;
-    L.tau = valid ? 3e-4f : INFINITY;
+    L.tau = valid ? RTUS_PLANAR_TAU : INFINITY;
     // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
     double cm = 0.0, h[NL], hr_l[NL], hc_l[NL], kk_l[NL];   // _l: in layer order
     L.inv_cm = 0.0;
@@ -151,7 +157,8 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
     L.rs0f = __builtin_amdgcn_rcpf(s0f) * (1.0f - 4e-6f);
     L.rhmf = __builtin_amdgcn_rcpf(hmf) * (1.0f - 4e-6f);
     L.asymf = asf * (1.0f + 4e-6f);
-    L.inv_cmf = (float)L.inv_cm;
+    L.hic = 0.5f * (float)L.inv_cm;
+    L.G = L.dG = 0.0f;
     L.hc0 = valid ? L.hc0 : NAN;                    // target not below the element: T = NaN falls out of the sums
     L.rS3 = 0.0f;
 }
@@ -162,42 +169,53 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
 // of the wave asks for a second Newton evaluation.
 // TAUP: the travel time from the tau-p form T = p X + sum (h_i / c_i) cos(theta_i) instead of T(q) + its Fermat expansion — see
 // the tail below.
-template <int NL, bool ITERS, bool FAST, bool TAUP>
-__device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL>& L, const ElemRec& R, int hist, double xf,
+template <int NL, bool ITERS, bool FAST, bool TAUP, int HOLD = 0>
+__device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL>& L, RecPtr R, int hist, double xf,
                                             float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f,
-                                            __amdgpu_buffer_rsrc_t rs, unsigned soff)
+                                            __amdgpu_buffer_rsrc_t rs, unsigned soff, float hold_age_rcp = 0.0f, bool* hold_ok = nullptr)
 {
-    const double dxs = xf - R.xe;
+    static_assert(HOLD == 0 || (FAST && TAUP), "HOLD is a mode of the tau-p tier's four-history runs");
+    const double dxs = xf - R->xe;
     const double X = fabs(dxs);
     // ---- Newton iteration in fp32 -----------------------------------------------------------
-    // The loop only has to bring q within 3e-4 of the root (the fp64 expansion below removes the
+    // The loop only has to bring q within tau of the root (the fp64 expansion below removes the
     // rest to third order), so it runs on the fp32 pipe: half the issue cost of fp64 and native
-    // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise three orders below
+    // v_rsq_f32 / v_rcp_f32.  X(q) = q S1 is evaluated to ~1e-7 relative: noise two orders below
     // the stopping threshold.  Lanes whose target is not below the element carry garbage
     // through the arithmetic (never a step: tau = +inf) and get NaN at the store.
-    const float Xf = (float)X;
+    // FAST (a four-history run) works on the SIGNED problem X(qs) = xf - xe — X(q) = q S1(q^2) is odd, the predictor's history is
+    // signed anyway — so the common path has no |.| to materialise and no sign to put back (a v_and and a v_bfi per solve); only
+    // the rare second-evaluation branch goes back to q >= 0, where the lower-bound clamp lives.
+    float Xf = FAST ? (float)dxs : (float)X;
+    double Xt = FAST ? dxs : X;                             // the reach that pairs with q in the tail (same sign as q)
     float y[NL], dq = 0.0f, dXf = 0.0f;                     // dq: the (small, untaken) Newton step of the last evaluation, dXf its residual
     int it = 0;
     // one evaluation of X(q), X'(q) on the fp32 pipe -> Newton step dq; y[] = the rsqrt seeds of this q
     auto eval = [&](float qq, bool second = false) {
         const float q2 = qq * qq;
         float S1 = L.hr0f, S3 = L.hr0f;                     // slot 0: k = 0, y = 1
+        const bool held = HOLD == 2 && !second;             // (compile-time where it matters: `second` is a literal at every call)
 #pragma unroll
         for (int i = 1; i < NL; ++i) {
             y[i] = __builtin_amdgcn_rsqf(fmaf(L.kkf[i], q2, 1.0f));
-            const float hw = L.hrf[i] * y[i];
-            S1 += hw;
-            S3 = fmaf(hw, y[i] * y[i], S3);
+            if (held) S1 = fmaf(L.hrf[i], y[i], S1);
+            else {
+                const float hw = L.hrf[i] * y[i];
+                S1 += hw;
+                S3 = fmaf(hw, y[i] * y[i], S3);
+            }
         }
         // 1 / X'(q).  tau-p tier on a four-history run: X' moves by well under 1 % from one element to the next, so ONE Newton step
-        // from the previous element's reciprocal (two FMAs, error = that change squared: < 1e-4) replaces the v_rcp_f32 (8.2 issue cycles)
-        if (TAUP && FAST && !second) L.rS3 = fmaf(fmaf(-S3, L.rS3, 1.0f), L.rS3, L.rS3);
+        // from the previous element's reciprocal (two FMAs, error = that change squared: < 1e-4) replaces the v_rcp_f32 (8.2 issue
+        // cycles) — or, HOLD = 2, the reciprocal of the group's first element serves the other three as it is (see the kernel)
+        if (held) {}
+        else if (TAUP && FAST && HOLD == 0 && !second) L.rS3 = fmaf(fmaf(-S3, L.rS3, 1.0f), L.rS3, L.rS3);
         else L.rS3 = __builtin_amdgcn_rcpf(S3);
         dXf = fmaf(-S1, qq, Xf);
         dq = dXf * L.rS3;
     };
     // two lower bounds of the root: X <= X'(0) q, and X <= hm q + asym (shaved so rounding keeps them lower)
-    auto lower_bound = [&]() { return fmaxf(fmaxf(Xf * L.rs0f, (Xf - L.asymf) * L.rhmf), 0.0f); };
+    auto lower_bound = [&]() { return fmaxf(fmaxf(fabsf(Xf) * L.rs0f, (fabsf(Xf) - L.asymf) * L.rhmf), 0.0f); };   // (FAST: Xf is signed)
     // Newton from q, every iterate clamped to lb.  A lane is done when the step it WOULD take is small; it does not
     // take it, so y[] stays the y of its q (and a done lane re-derives the same small dq on later trips: no state needed).
     auto newton = [&](float& q, float lb) {
@@ -212,34 +230,46 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
     float q;
     if (FAST) {
         // the cubic extrapolation is nearly always within tau of the root: one evaluation, no clamp, no select
-        q = fabsf(fmaf(R.w1, h1, fmaf(R.w2, h2, fmaf(R.w3, h3, R.w4 * h4))));
+        q = fmaf(R->w1, h1, fmaf(R->w2, h2, fmaf(R->w3, h3, R->w4 * h4)));
         eval(q);
 #ifdef RTUS_EXP_COUNT   // experiment builds only (scripts/exp_planar_miss.py): how far the cubic predictor lands from the root
         if (live && L.tau < 1.0f) {
-            const float rel = fabsf(dq) / q;
+            const float rel = fabsf(dq) / fabsf(q);
             atomicAdd(&planar_dbg[0], 1ull);
-            if (rel > 1e-7f) atomicAdd(&planar_dbg[1], 1ull);
-            if (rel > 3e-7f) atomicAdd(&planar_dbg[2], 1ull);
-            if (rel > 1e-6f) atomicAdd(&planar_dbg[3], 1ull);
-            if (rel > 3e-6f) atomicAdd(&planar_dbg[4], 1ull);
-            if (rel > 1e-5f) atomicAdd(&planar_dbg[5], 1ull);
-            if (rel > 1e-4f) atomicAdd(&planar_dbg[6], 1ull);
+            if (rel > 3e-5f) atomicAdd(&planar_dbg[1], 1ull);
             atomicMax((unsigned long long*)&planar_dbg[7], (unsigned long long)__float_as_uint(rel));
         }
+        {   // waves with any lane beyond 3e-5 / 5e-5 / 1e-4
+            const float relw = (live && L.tau < 1.0f) ? fabsf(dq) / fabsf(q) : 0.0f;
+            const bool l0 = (threadIdx.x & 63) == 0;
+            if (__ballot(relw > 3e-5f) && l0) atomicAdd(&planar_dbg[2], 1ull);
+            if (__ballot(relw > 5e-5f) && l0) atomicAdd(&planar_dbg[3], 1ull);
+            if (__ballot(relw > 1e-4f) && l0) atomicAdd(&planar_dbg[4], 1ull);
+        }
 #endif
-        const bool big = fabsf(dq) > L.tau * q;
-        if (__builtin_amdgcn_ballot_w64(big)) {             // rare (wave-uniform): some lane wants a second evaluation
+        // (a prediction of the wrong sign is never "small": the step it asks for is larger than itself)
+        const bool big = fabsf(dq) > L.tau * fabsf(q);
+        if (__builtin_amdgcn_ballot_w64(big)) {             // wave-uniform: some lane wants a second evaluation
             asm volatile("" : "+v"(q));                     // keeps this block a branch (nothing of it is speculated)
-            const float lb = lower_bound();
-            q = big ? fmaxf(q + dq, lb) : q;
+            // Newton on the signed problem, clamped to the signed lower bound: max(., lb) for targets to the right of the element,
+            // min(., -lb) to the left = the median with that side's infinity (one v_med3_f32 either way)
+            const float sgb = __int_as_float(__double2hiint(dxs));
+            const float lbs = __builtin_copysignf(lower_bound(), sgb), sinf = __builtin_copysignf(INFINITY, sgb);
+            q = big ? __builtin_amdgcn_fmed3f(q + dq, lbs, sinf) : q;
             if (ITERS) it += big ? 1 : 0;
-            newton(q, lb);
+            for (int trip = 0; trip < 64; ++trip) {         // wave-uniform trip count, ballot exit
+                eval(q, true);
+                const bool bigger = fabsf(dq) > L.tau * fabsf(q);
+                if (!__builtin_amdgcn_ballot_w64(bigger)) break;
+                q = bigger ? __builtin_amdgcn_fmed3f(q + dq, lbs, sinf) : q;
+                if (ITERS) it += bigger ? 1 : 0;
+            }
         }
     } else {
         const float lb = lower_bound();
         q = lb;
         if (hist > 0)                                       // wave-uniform; unused weights are 0
-            q = fmaxf(fabsf(fmaf(R.w1, h1, fmaf(R.w2, h2, fmaf(R.w3, h3, R.w4 * h4)))), lb);
+            q = fmaxf(fabsf(fmaf(R->w1, h1, fmaf(R->w2, h2, fmaf(R->w3, h3, R->w4 * h4)))), lb);
         newton(q, lb);
     }
     // ---- fp64: accurate T at q + the Fermat expansion in the residual dXr = X - X(q) ----------
@@ -259,7 +289,7 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
             A1 = fma(L.hr[i], w, A1);
             ST = fma(L.hc[i], w, ST);
         }
-        const double dXr = fma(-A1, qd, X);
+        const double dXr = fma(-A1, qd, Xt);
         // T = T(q) + dXr (u/cm) (q + (u^2 / (2 X'(q))) dXr) = u (a1 ST + (dXr / cm) (q + s2 dXr)): the coefficient s2 only
         // scales the 2nd-order term (relative size (dXr/X)^2 ~ 1e-7), so it is formed on the fp32 pipe from the seeds.
         const float s2 = (0.5f * us) * (us * L.rS3);
@@ -280,8 +310,19 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
             const double t = fma(-g, g, d) * yi;            // ... and one Newton step: sqrt(d) = g + t / 2 (error ~1e-14)
             ST = fma(L.hc[i], fma(t, 0.5, g), ST);
         }
-        const float Sf = (0.5f * us) * (us * us) * (L.inv_cmf * (dq * dXf));
-        T = fma(u, fma(qd * L.inv_cm, X, ST), (double)Sf);
+        // the second-order term = G dXf^2 with G = u^3 / (2 cm X'(q)); HOLD = 2: the G of the group's first element (see the kernel)
+        float G;
+        if (HOLD == 2) G = L.G = L.G + L.dG;                // one element further along the line through the last two G formed
+        else {
+            G = ((L.hic * us) * (us * us)) * L.rS3;
+            if (HOLD == 1) {
+                L.dG = (G - L.G) * hold_age_rcp;                // hold_age_rcp here: 1 / (elements since L.G was formed)
+                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G);   // (lanes without a path: NaN, never true)
+            }
+            L.G = G;
+        }
+        const float Sf = (G * dXf) * dXf;
+        T = fma(u, fma(qd * L.inv_cm, Xt, ST), (double)Sf);
     }
     // store through the workgroup's buffer descriptor (base: its first output row, extent: its block of rows): the
     // element's row enters as the scalar offset, each lane supplies a 32-bit byte offset (no 64-bit per-lane address
@@ -292,9 +333,9 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
         __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, soff, 0);
         if (ITERS && live) (iters + row)[f] = (uint8_t)it;
     }
-    // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe
+    // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe (FAST: it has it)
     const float qroot = q + dq;
-    return __builtin_copysignf(qroot, __int_as_float(__double2hiint(dxs)));    // one v_bfi_b32
+    return FAST ? qroot : __builtin_copysignf(qroot, __int_as_float(__double2hiint(dxs)));    // one v_bfi_b32
 }
 
 // A workgroup = 256 focal points x `eb` consecutive elements (loop).  Besides re-using the layer
@@ -390,8 +431,9 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     }
     __syncthreads();
 
+    const RecPtr rec3 = (RecPtr)rec;
     Lane<NL> L;
-    L.tau = INFINITY; L.rS3 = 0.0f; L.inv_cm = 0.0; L.hr0 = L.hc0 = 0.0; L.hr0f = L.rs0f = L.rhmf = L.asymf = 0.0f;
+    L.tau = INFINITY; L.rS3 = 0.0f; L.G = L.dG = 0.0f; L.hic = 0.0f; L.inv_cm = 0.0; L.hr0 = L.hc0 = 0.0; L.hr0f = L.rs0f = L.rhmf = L.asymf = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) { L.hr[i] = L.kk[i] = L.hc[i] = 0.0; L.hrf[i] = L.kkf[i] = 0.0f; }
     float qa = 0.0f, qb = 0.0f, qc = 0.0f, qd = 0.0f;       // signed solutions of the four previous elements, qa the latest
@@ -418,17 +460,54 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         }
         const int run4 = (info >> 8) & ~3;
         if (run4 > 0) {
-            // four-history run, unrolled by four so that the history rotates through its registers without moves
+            // four-history run, unrolled by four so that the history rotates through its registers without moves.  The records are
+            // read at ONE per-lane address register advanced once per trip, with immediate offsets (left to itself the compiler
+            // forms each record's address on the scalar unit and pays a v_mov per ds_read: two VALU slots per solve)
+            unsigned rp_off = (unsigned)li * (unsigned)sizeof(ElemRec);
+            asm volatile("" : "+v"(rp_off));
+            RecPtr rp = (RecPtr)((const __attribute__((address_space(3))) char*)rec3 + rp_off);
+            // HOLD (tau-p tier).  The untaken Newton step dq = dXf / X' and the tail's second-order term G dXf^2 need X'(q) and u^3
+            // only to a few per cent — dq moves the history by <= tau q, the term is <= (tau^2 / 8) T — and both drift by ~1-2 % from
+            // one element to the next.  So the FIRST solve of a group of four forms them exactly (HOLD = 1: the sum for X', v_rcp_f32,
+            // u^3) and, when G moved by less than 3 % per element since it was last formed (wave-uniform test), the other three reuse
+            // them (HOLD = 2: eleven fp32 instructions fewer per solve); otherwise they run as before (HOLD = 0: Newton-updated
+            // reciprocal).  Error of the held term: <= ~10 % of (tau^2 / 8) T = 3e-11 T at the stopping threshold, 1e-15 T typically.
+            // A row's bits stay a function of the table (the groups start where the four-history run starts: a function of the
+            // aperture and of the rows per block).
+            bool held = false;                              // L.G is one element old (else: four)
             for (int r = 0; r < run4; r += 4) {
-                qd = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 0], 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
-                qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 1], 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
-                qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 2], 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
-                qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rec[li + r + 3], 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+#ifdef RTUS_EXP_NO_HOLD
+                if (false) {
+#else
+                if (TAUP) {
+#endif
+                    bool ok = false;
+                    qd = solve_elem<NL, ITERS, true, TAUP, TAUP ? 1 : 0>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so), held ? 0.25f : 1.0f, &ok);
+                    if (ok) {
+                        qc = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                        qb = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                        qa = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                    } else {
+                        qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                        qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                        qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                    }
+                    held = ok;
+#ifdef RTUS_EXP_COUNT   // groups of four, and how many of them reused the first solve's X' and u^3
+                    if ((threadIdx.x & 63) == 0) { atomicAdd(&planar_dbg[5], 1ull); if (ok) atomicAdd(&planar_dbg[6], 1ull); }
+#endif
+                } else {
+                    qd = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
+                    qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                    qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                    qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                }
                 o += 4 * nf; so += 4 * row_bytes;
+                rp += 4;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false, TAUP>(it_p, L, rec[li], info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
+            const float qn = solve_elem<NL, ITERS, false, TAUP>(it_p, L, rec3 + li, info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf; so += row_bytes;
             ++li;
@@ -522,12 +601,18 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     const dim3 grid(a.gx, a.gy, n_batch), block(RTUS_BLOCK);
 #endif
     const bool taup = (flags & RTUS_TT_TAUP_TAIL) != 0;
+    // Workgroups per CU.  The registers allow 8 (the 64-VGPR kernels: up to three layers), and a launch of 16 per CU then runs as two
+    // rounds that start and end together — every wave of a SIMD in the same phase of its block (cold start / four-history run) at the
+    // same time.  Asking for 24 KB of LDS the kernel never touches caps it at SIX per CU: the rounds overlap, the launch is 3.5 %
+    // shorter on BASELINE configs[2] (7: -2.5 %, 5: +0.8 %, 4: +1.4 %, 3: +6.7 %; a launch of one round: +0.6 %, so only from two
+    // rounds on).  (4096 = 16 x the 256 CUs of the one part this library is written for.)
+    const unsigned lds = (n_if + 1 <= 3 && !iters && items >= 4096) ? 24u * 1024u : 0u;
     switch (n_if + 1) {
-#define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, 0, s, a); \
-                               else if (row_of && taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, true>), grid, block, 0, s, a); \
-                               else if (row_of) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, true>), grid, block, 0, s, a); \
-                               else if (taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, false>), grid, block, 0, s, a); \
-                               else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, false>), grid, block, 0, s, a); break;
+#define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, lds, s, a); \
+                               else if (row_of && taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, true>), grid, block, lds, s, a); \
+                               else if (row_of) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, true>), grid, block, lds, s, a); \
+                               else if (taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, false>), grid, block, lds, s, a); \
+                               else hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, false, false>), grid, block, lds, s, a); break;
         RTUS_CASE(1) RTUS_CASE(2) RTUS_CASE(3) RTUS_CASE(4) RTUS_CASE(5) RTUS_CASE(6) RTUS_CASE(7) RTUS_CASE(8)
         RTUS_CASE(9)
 #undef RTUS_CASE

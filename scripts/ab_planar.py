@@ -20,7 +20,12 @@ def load(path):
     dp, ip, vp = C.c_void_p, C.c_int, C.c_void_p
     L.rtus_tt_layers_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, vp]
     L.rtus_tt_layers_dev.restype = ip
+    L.rtus_tt_layers_ex_dev.argtypes = [dp, dp, ip, dp, dp, ip, dp, dp, ip, dp, vp, C.c_uint, vp]
+    L.rtus_tt_layers_ex_dev.restype = ip
     return L
+
+
+TIER = 1 if os.environ.get("AB_TAUP") else 0          # RTUS_TT_TAUP_TAIL: the tier the headline times
 
 
 def main():
@@ -36,9 +41,9 @@ def main():
         xe, ze, xf, zf = t64(W["xe"]), t64(W["ze"]), t64(W["xf"]), t64(W["zf"])
         outs = [torch.empty((W["n_e"], W["n_f"]), dtype=torch.float64, device=dev) for _ in libs]
         def run(i):
-            st = libs[i].rtus_tt_layers_dev(z_if.ctypes.data, c.ctypes.data, z_if.size, xe.data_ptr(), ze.data_ptr(), W["n_e"],
-                                            xf.data_ptr(), zf.data_ptr(), W["n_f"], outs[i].data_ptr(), None,
-                                            torch.cuda.current_stream().cuda_stream)
+            st = libs[i].rtus_tt_layers_ex_dev(z_if.ctypes.data, c.ctypes.data, z_if.size, xe.data_ptr(), ze.data_ptr(), W["n_e"],
+                                               xf.data_ptr(), zf.data_ptr(), W["n_f"], outs[i].data_ptr(), None, TIER,
+                                               torch.cuda.current_stream().cuda_stream)
             assert st == 0, st
 
         graphs = []

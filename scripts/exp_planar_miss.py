@@ -19,4 +19,4 @@ for name in ("cfg3_planar", "cfg2_planar"):
     L.rtus_dbg_read_planar(buf)
     v = list(buf)
     mx = struct.unpack("f", struct.pack("I", v[7] & 0xffffffff))[0]
-    print(name, "four-history solves", v[0], "| miss > 1e-7:", v[1], "> 3e-7:", v[2], "> 1e-6:", v[3], "> 3e-6:", v[4], "> 1e-5:", v[5], "> 1e-4:", v[6], "| max %.3e" % mx)
+    print(name, "four-history solves", v[0], "| miss > 3e-5:", v[1], "| WAVES (of %d) with a lane > 3e-5:" % (v[0] // 64), v[2], "> 5e-5:", v[3], "> 1e-4:", v[4], "| groups of four:", v[5], "held:", v[6], "| max %.3e" % mx)
