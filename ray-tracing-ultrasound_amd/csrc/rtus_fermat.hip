@@ -82,7 +82,8 @@ struct __attribute__((aligned(16))) ElemRec {
     float w1, w2, w3, w4;   // extrapolation weights on the signed solutions of the four previous elements
     double xe;
     int info;               // bits 0-2: previous elements usable as history (0..4); bit 3: depth differs from the previous
-                            // element's (layer set-up needed); bits 8..: length of the run of 4-history elements starting here
+                            // element's (layer set-up needed); bit 4: uniform pitch from four elements behind to three ahead (HOLD);
+                            // bits 8..: length of the run of 4-history elements starting here
     int row;                // PERM: the element's output row
 };
 
@@ -317,7 +318,8 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
             G = ((L.hic * us) * (us * us)) * L.rS3;
             if (HOLD == 1) {
                 L.dG = (G - L.G) * hold_age_rcp;                // hold_age_rcp here: 1 / (elements since L.G was formed)
-                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G);   // (lanes without a path: NaN, never true)
+                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G) &&      // (lanes without a path: NaN, never true)
+                           (__builtin_amdgcn_readfirstlane(R->info) & 16);            // the pitch is uniform around this group
             }
             L.G = G;
         }
@@ -420,12 +422,24 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         const unsigned long long m4 = __ballot(m == 4 && lane < ne);
         const unsigned long long rest = ~(m4 >> lane);
         const int run = (m == 4 && lane < ne) ? (rest ? __ffsll((long long)rest) - 1 : 64 - lane) : 0;
+        // HOLD (tau-p tier) extrapolates along the ELEMENT INDEX: only where the pitch is uniform (2 %) over the four elements behind
+        // and the three ahead (an aperture of random spacing put 4.5e-9 relative on a table before this test existed —
+        // tests/test_gpu_irregular_apertures.py::test_planar_taup_tier_irregular_and_coarse_apertures).  Behind: this lane's own
+        // differences; ahead: the same statement of the lane three further on (they share the step x_i - x_(i-1)).  No loads, no LDS
+        // word of its own: the workgroup's start-up is not overlapped with anything (0.1 us there is 1 % of a configs[1] launch).
+        bool uni = false;
+        if (TAUP && a.eb >= 8) {                            // (a block of fewer rows has no group of four behind four cold rows)
+            const float tolu = 0.02f * fabsf(t1);
+            const bool ub = m == 4 && lane < ne && fabsf(d12 - t1) <= tolu && fabsf(d23 - t1) <= tolu && fabsf(d34 - t1) <= tolu;
+            const unsigned long long ubm = __ballot(ub);
+            uni = __builtin_amdgcn_inverse_ballot_w64(ubm & (ubm >> 3));
+        }
         ElemRec r;
 #ifdef RTUS_EXP_BAD_PREDICTOR                               // experiment builds only (scripts/selftest_predictor.sh): the continuation tests must notice
         w1 *= 1.02f; w3 *= 0.97f;
 #endif
         r.w1 = w1; r.w2 = w2; r.w3 = w3; r.w4 = w4; r.xe = x0;
-        r.info = m | (hist == 0 ? 8 : 0) | (run << 8);
+        r.info = m | (hist == 0 ? 8 : 0) | (uni ? 16 : 0) | (run << 8);
         r.row = PERM ? a.row_of[el] : 0;
         rec[lane] = r;
     }
@@ -469,8 +483,8 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
             // HOLD (tau-p tier).  The untaken Newton step dq = dXf / X' and the tail's second-order term G dXf^2 need X'(q) and u^3
             // only to a few per cent — dq moves the history by <= tau q, the term is <= (tau^2 / 8) T — and both drift by ~1-2 % from
             // one element to the next.  So the FIRST solve of a group of four forms them exactly (HOLD = 1: the sum for X', v_rcp_f32,
-            // u^3) and, when G moved by less than 3 % per element since it was last formed (wave-uniform test), the other three reuse
-            // them (HOLD = 2: eleven fp32 instructions fewer per solve); otherwise they run as before (HOLD = 0: Newton-updated
+            // u^3) and, when G moved by less than 3 % per element since it was last formed (wave-uniform test) and the pitch is uniform
+            // around the group (bit 4 of the record: the extrapolation runs along the element index), the other three reuse them (HOLD = 2: eleven fp32 instructions fewer per solve); otherwise they run as before (HOLD = 0: Newton-updated
             // reciprocal).  Error of the held term: <= ~10 % of (tau^2 / 8) T = 3e-11 T at the stopping threshold, 1e-15 T typically.
             // A row's bits stay a function of the table (the groups start where the four-history run starts: a function of the
             // aperture and of the rows per block).

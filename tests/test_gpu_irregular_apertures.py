@@ -56,6 +56,38 @@ def _apertures():
 
 
 @pytest.mark.parametrize("media", [([0.020], [2330.0, 1483.0]), ([0.010, 0.025], [1483.0, 5900.0, 2330.0])])
+def test_planar_taup_tier_irregular_and_coarse_apertures(rtus, media):
+    """The tau-p tier's four-history runs reuse 1/X' and u^3/(2 cm X') of a group's first solve in the other three when they drift
+    by < 3 % per element (rtus_fermat.hip, HOLD) and form them per solve otherwise: apertures whose runs are all held (fine pitch),
+    none held (5 mm pitch: tens of per cent per element), and mixed, in any order (rtus.travel_time_layers sorts: the PERM kernel) —
+    every entry of sampled rows against the long-double oracle at the tier's bar, and against the accurate tier."""
+    from oracle import cport
+    z_if, c = media
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, GRID[0]), np.linspace(0.004, 0.06, GRID[1]))
+    xf, zf = xs.ravel(), zs.ravel()
+    assert _dev().rows_per_block(40, xf.size) >= 8
+    rng = np.random.default_rng(3)
+    cases = list(_apertures())
+    cases.append(("coarse 5 mm", (np.arange(40) - 19.5) * 5e-3, np.zeros(40)))
+    cases.append(("fine then coarse", np.concatenate([(np.arange(20) - 30) * 0.3e-3, 0.001 + np.arange(20) * 4e-3]), np.zeros(40)))
+    cases.append(("random spacing", np.sort(rng.uniform(-0.03, 0.03, 40)), np.zeros(40)))
+    rows = [0, 3, 4, 5, 7, 8, 12, 19, 20, 21, 27, 39]
+    worst = 0.0
+    for name, xe, ze in cases:
+        fast = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, taup=True)
+        acc = rtus.travel_time_layers(z_if, c, xe, ze, xf, zf)
+        ok = zf[None, :] > ze[:, None]
+        assert np.isnan(fast[~ok]).all() and np.isfinite(fast[ok]).all(), name
+        ref = cport.tt_layers(z_if, c, xe[rows], ze[rows], xf, zf)
+        rel = (np.abs(fast[rows] - ref) / ref)[ok[rows]]
+        assert rel.max() < 6e-11, (name, float(rel.max()))                      # the tier's bar (include/rtus.h)
+        assert np.max(np.abs(fast[rows] - ref)[ok[rows]]) < 1e-15, name
+        assert np.max((np.abs(fast - acc) / acc)[ok]) < 6e-11, name
+        worst = max(worst, float(rel.max()))
+    print(f"tau-p tier on {len(cases)} apertures: worst relative error vs the oracle {worst:.2e}")
+
+
+@pytest.mark.parametrize("media", [([0.020], [2330.0, 1483.0]), ([0.010, 0.025], [1483.0, 5900.0, 2330.0])])
 def test_planar_irregular_apertures(rtus, media):
     from oracle import cport
     z_if, c = media
