@@ -91,9 +91,9 @@ typedef const __attribute__((address_space(3))) ElemRec* RecPtr;   // a record w
 
 // Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
 // traversed layer (there k = 0 and w = (1 + k q^2)^(-1/2) = 1 exactly: slot 0 needs no rsqrt anywhere).
-#ifndef RTUS_PLANAR_TAU
-#define RTUS_PLANAR_TAU 3e-4f   // relative size of the Newton step at which a lane stops (and does not take it)
-#endif
+// relative size of the Newton step at which a lane stops (and does not take it).  A HELD solve of the tau-p tier (HOLD = 2) forms its
+// second-order term from quantities good to ~1 % (3 % at worst): its error is that fraction of (tau^2 / 8) T, so it stops at a third
+#define RTUS_PLANAR_TAU 3e-4f
 template <int NL>
 struct Lane {
     double hr0, hc0, hr[NL], kk[NL], hc[NL], inv_cm;       // slots 1 .. NL-1 of the arrays are used
@@ -206,12 +206,11 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
                 S3 = fmaf(hw, y[i] * y[i], S3);
             }
         }
-        // 1 / X'(q).  tau-p tier on a four-history run: X' moves by well under 1 % from one element to the next, so ONE Newton step
-        // from the previous element's reciprocal (two FMAs, error = that change squared: < 1e-4) replaces the v_rcp_f32 (8.2 issue
-        // cycles) — or, HOLD = 2, the reciprocal of the group's first element serves the other three as it is (see the kernel)
-        if (held) {}
-        else if (TAUP && FAST && HOLD == 0 && !second) L.rS3 = fmaf(fmaf(-S3, L.rS3, 1.0f), L.rS3, L.rS3);
-        else L.rS3 = __builtin_amdgcn_rcpf(S3);
+        // 1 / X'(q): v_rcp_f32 — or, HOLD = 2, the reciprocal of the group's first element as it is (see the kernel).  (Round 3 took
+        // ONE Newton step from the previous element's reciprocal instead, error = the change of X' squared: fine on a fine regular
+        // pitch, but on a coarse or random one — X' moving by tens of per cent per element, the predictor missing by ~tau — it put
+        // 2.8e-10 relative on a table: scripts/fuzz_layers.py --taup with tables large enough for four-history runs found it.)
+        if (!held) L.rS3 = __builtin_amdgcn_rcpf(S3);
         dXf = fmaf(-S1, qq, Xf);
         dq = dXf * L.rS3;
     };
@@ -249,7 +248,8 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
         }
 #endif
         // (a prediction of the wrong sign is never "small": the step it asks for is larger than itself)
-        const bool big = fabsf(dq) > L.tau * fabsf(q);
+        const float tau_f = HOLD == 2 ? L.tau * (1.0f / 3.0f) : L.tau;   // (loop-invariant: one register, no instruction per solve)
+        const bool big = fabsf(dq) > tau_f * fabsf(q);
         if (__builtin_amdgcn_ballot_w64(big)) {             // wave-uniform: some lane wants a second evaluation
             asm volatile("" : "+v"(q));                     // keeps this block a branch (nothing of it is speculated)
             // Newton on the signed problem, clamped to the signed lower bound: max(., lb) for targets to the right of the element,
@@ -318,7 +318,10 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
             G = ((L.hic * us) * (us * us)) * L.rS3;
             if (HOLD == 1) {
                 L.dG = (G - L.G) * hold_age_rcp;                // hold_age_rcp here: 1 / (elements since L.G was formed)
-                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G) &&      // (lanes without a path: NaN, never true)
+                // G is a smooth function of q (|d ln G / dq| <= 3): a step of the root of <= 0.02 per element keeps the line through the
+                // last two G within ~1 % of G over the three elements ahead, and rules out a group that straddles the extremum of G
+                // under a target (first difference ~0, second difference not)
+                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G || fabsf(h1 - h2) > 0.02f) &&   // (lanes without a path: NaN, never true)
                            (__builtin_amdgcn_readfirstlane(R->info) & 16);            // the pitch is uniform around this group
             }
             L.G = G;

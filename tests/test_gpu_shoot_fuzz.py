@@ -43,6 +43,17 @@ def test_fuzz_planar_layers_vs_oracle(rtus):
     assert "OK: 60 trials" in r.stdout
 
 
+def test_fuzz_planar_layers_taup_tier_vs_oracle(rtus):
+    """The same fuzz through the tau-p tier (device-side sorted entry), bar 1e-16 s + 6e-11 t; every fourth trial is a table large
+    enough for >= 8 rows per workgroup (asserted in the script): the four-history runs and the held groups of rtus_fermat.hip.
+    (Those trials were added in round 4 and found round 3's tier 2.8e-10 off on a coarse random aperture — the reciprocal of X' taken
+    by one Newton step from the previous element's — and the first version of the held groups 5.8e-10 off under a target.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_layers.py"), "48", "77", "--taup"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK (tau-p tier, sorted entry): 48 trials" in r.stdout
+
+
 def test_fuzz_lens_kernels_vs_oracle(rtus):
     """scripts/fuzz_lens.py: curved-lens Fermat kernels (fp64 + fp32) vs the golden-section oracle on random apertures /
     targets / sizes; 25 trials here (long run: 150 trials, 0.2 M solves, worst 4.7e-20 s fp64, 2.1e-11 s fp32)."""
