@@ -39,7 +39,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PREWARM_MS = 30.0              # untimed graph replays before the timed region (clock ramp), disclosed in config
+PREWARM_MS = 300.0             # untimed graph replays before the timed region (clock ramp), disclosed in config.  Measured on the
+                               # headline (scripts/exp_bench_prewarm.sh, K = 20, three rounds per value, two boxes): 0 ms 0.185 ms per step,
+                               # 3 ms 0.163, 30 ms 0.1385 / 0.1334, 300 ms 0.1352 / 0.1327, 1000 ms 0.139 - 0.149 (the power cap answers):
+                               # an MI355X leaving idle needs a few hundred ms of load to reach the clock it then holds
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
 PLANAR = ("cfg2_planar", "cfg3_planar", "cfg5_fmc")
@@ -217,12 +220,12 @@ class Timed:
                         self.step(s)
         torch.cuda.current_stream().wait_stream(side)
         # untimed replays: the first uploads the graph; then keep the GPU busy for PREWARM_MS so that the timed region
-        # starts at the sustained clock whatever K is (an idle MI355X needs a few ms of load to bring its clocks up)
+        # starts at the sustained clock whatever K is (an idle MI355X needs a few hundred ms of load to bring its clocks up)
         t_pre = time.perf_counter()
         g.replay()
         torch.cuda.synchronize()
         one = max(time.perf_counter() - t_pre, 1e-5)
-        for _ in range(min(200, int(PREWARM_MS * 1e-3 / one))):
+        for _ in range(min(max(1, 4000 // self.steps), int(PREWARM_MS * 1e-3 / one))):     # (at most ~4,000 launches: short kernels ramp less)
             g.replay()
         torch.cuda.synchronize()
         return g

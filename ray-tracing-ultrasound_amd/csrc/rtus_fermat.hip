@@ -105,8 +105,14 @@ struct Lane {
 };
 
 template <int NL>
-__device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, double zf, Lane<NL>& L)
+__device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, const double* __restrict__ zf_p, unsigned f, Lane<NL>& L)
 {
+    // The target's depth is needed here and nowhere else, and the set-up runs once per depth of the aperture: it is LOADED here (an
+    // L2 hit), through an index the compiler cannot see through.  Left to itself it keeps zf — and the parts of the set-up that
+    // depend on the target alone, hoisted out of the element loop: four more doubles — in SCRATCH across the loop (no register is
+    // free for them): 6 % more HBM writes per launch than the table itself (rocprofv3 WRITE_SIZE), now none.
+    asm volatile("" : "+v"(f));
+    const double zf = zf_p[f];
     const bool valid = zf > ze;
     L.tau = valid ? RTUS_PLANAR_TAU : INFINITY;
     // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
@@ -114,8 +120,10 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, doubl
     L.inv_cm = 0.0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const double top = (i == 0) ? ze : fmax(a.z_if[i - 1], ze);
-        const double bot = (i < NL - 1) ? fmin(a.z_if[i], zf) : zf;
+        // (selects, not fmax / fmin: those quiet their operands first — a v_max_f64 of each interface depth with itself, loop-invariant,
+        // hoisted and then parked in scratch like zf above; the interface depths are finite or +inf, never NaN)
+        const double top = (i == 0) ? ze : (a.z_if[i - 1] > ze ? a.z_if[i - 1] : ze);
+        const double bot = (i < NL - 1) ? (a.z_if[i] < zf ? a.z_if[i] : zf) : zf;
         h[i] = fmax(bot - top, 0.0);
         const bool faster = h[i] > 0.0 && a.c[i] > cm;
         cm = faster ? a.c[i] : cm;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     const int f_raw = bx * RTUS_BLOCK + threadIdx.x;
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
-    const double xf = xf_p[f], zf = zf_p[f];
+    const double xf = xf_p[f];
     const int gb = a.row0 / a.eb + by;                      // the workgroup's block of the whole table
     const int e0 = max(gb * a.eb - a.row0, 0);              // ... in this launch's rows (a shard that starts inside a block keeps its tail)
     const int ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;   // elements of this workgroup (<= 64)
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
         if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
-            layer_setup<NL>(a, ze_p[e0 + li], zf, L);
+            layer_setup<NL>(a, ze_p[e0 + li], zf_p, (unsigned)f, L);
             qa = qb = qc = qd = 0.0f;                        // a lane may carry NaN history from a depth at which its target
                                                              // was not below the element
         }
@@ -623,7 +631,11 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     // same time.  Asking for 24 KB of LDS the kernel never touches caps it at SIX per CU: the rounds overlap, the launch is 3.5 %
     // shorter on BASELINE configs[2] (7: -2.5 %, 5: +0.8 %, 4: +1.4 %, 3: +6.7 %; a launch of one round: +0.6 %, so only from two
     // rounds on).  (4096 = 16 x the 256 CUs of the one part this library is written for.)
+#ifdef RTUS_EXP_PERSIST                                      // (the persistent grid is the experiment with ALL eight slots per SIMD taken)
+    const unsigned lds = 0u;
+#else
     const unsigned lds = (n_if + 1 <= 3 && !iters && items >= 4096) ? 24u * 1024u : 0u;
+#endif
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, lds, s, a); \
                                else if (row_of && taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, true>), grid, block, lds, s, a); \
