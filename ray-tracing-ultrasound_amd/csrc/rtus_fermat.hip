@@ -105,14 +105,14 @@ struct Lane {
 };
 
 template <int NL>
-__device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, const double* __restrict__ zf_p, unsigned f, Lane<NL>& L)
+__device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, const double* __restrict__ zf_p, unsigned f8, Lane<NL>& L)
 {
     // The target's depth is needed here and nowhere else, and the set-up runs once per depth of the aperture: it is LOADED here (an
     // L2 hit), through an index the compiler cannot see through.  Left to itself it keeps zf — and the parts of the set-up that
     // depend on the target alone, hoisted out of the element loop: four more doubles — in SCRATCH across the loop (no register is
     // free for them): 6 % more HBM writes per launch than the table itself (rocprofv3 WRITE_SIZE), now none.
-    asm volatile("" : "+v"(f));
-    const double zf = zf_p[f];
+    asm volatile("" : "+v"(f8));
+    const double zf = *(const double*)((const char*)zf_p + f8);   // (the byte offset the stores use anyway: no second index register)
     const bool valid = zf > ze;
     L.tau = valid ? RTUS_PLANAR_TAU : INFINITY;
     // thickness of each layer along the path (0 for layers the path does not enter); fastest speed
@@ -180,7 +180,7 @@ __device__ __forceinline__ void layer_setup(const LayerArgs& a, double ze, const
 // the tail below.
 template <int NL, bool ITERS, bool FAST, bool TAUP, int HOLD = 0>
 __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL>& L, RecPtr R, int hist, double xf,
-                                            float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f,
+                                            float h1, float h2, float h3, float h4, bool live, size_t row, unsigned f8,
                                             __amdgpu_buffer_rsrc_t rs, unsigned soff, float hold_age_rcp = 0.0f, bool* hold_ok = nullptr)
 {
     static_assert(HOLD == 0 || (FAST && TAUP), "HOLD is a mode of the tau-p tier's four-history runs");
@@ -343,8 +343,8 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
     // to its address (gfx950 range-checks scalar + lane offset together, so a one-row extent cannot drop them)
     {
         const u32x2 bits = {(unsigned)__double2loint(T), (unsigned)__double2hiint(T)};
-        __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f * 8u, soff, 0);
-        if (ITERS && live) (iters + row)[f] = (uint8_t)it;
+        __builtin_amdgcn_raw_buffer_store_b64(bits, rs, f8, soff, 0);        // f8: the target's byte offset in a row (8 f)
+        if (ITERS && live) (iters + row)[f8 >> 3] = (uint8_t)it;
     }
     // history for the predictor (fp32): the root itself, q + (untaken step), with the sign of xf - xe (FAST: it has it)
     const float qroot = q + dq;
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     const bool live = f_raw < a.n_f;
     const int f = live ? f_raw : a.n_f - 1;
     const double xf = xf_p[f];
+    const unsigned f8 = (unsigned)f * 8u;                   // the target's byte offset in a row of the table (n_f x 8 < 2^32: the launcher checks)
     const int gb = a.row0 / a.eb + by;                      // the workgroup's block of the whole table
     const int e0 = max(gb * a.eb - a.row0, 0);              // ... in this launch's rows (a shard that starts inside a block keeps its tail)
     const int ne = min((gb + 1) * a.eb - a.row0, a.n_e) - e0;   // elements of this workgroup (<= 64)
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
     while (li < ne) {                                        // wave-uniform loop
         const int info = __builtin_amdgcn_readfirstlane(rec[li].info);
         if (info & 8) {                                      // depth changed: redo the layer set-up, forget the history
-            layer_setup<NL>(a, ze_p[e0 + li], zf_p, (unsigned)f, L);
+            layer_setup<NL>(a, ze_p[e0 + li], zf_p, f8, L);
             qa = qb = qc = qd = 0.0f;                        // a lane may carry NaN history from a depth at which its target
                                                              // was not below the element
         }
@@ -507,32 +508,32 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
                 if (TAUP) {
 #endif
                     bool ok = false;
-                    qd = solve_elem<NL, ITERS, true, TAUP, TAUP ? 1 : 0>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so), held ? 0.25f : 1.0f, &ok);
+                    qd = solve_elem<NL, ITERS, true, TAUP, TAUP ? 1 : 0>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), f8, dest_rs(li + r, o), dest_so(so), held ? 0.25f : 1.0f, &ok);
                     if (ok) {
-                        qc = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
-                        qb = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
-                        qa = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                        qc = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), f8, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                        qb = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), f8, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                        qa = solve_elem<NL, ITERS, true, TAUP, TAUP ? 2 : 0>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), f8, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
                     } else {
-                        qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
-                        qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
-                        qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                        qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), f8, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                        qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), f8, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                        qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), f8, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
                     }
                     held = ok;
 #ifdef RTUS_EXP_COUNT   // groups of four, and how many of them reused the first solve's X' and u^3
                     if ((threadIdx.x & 63) == 0) { atomicAdd(&planar_dbg[5], 1ull); if (ok) atomicAdd(&planar_dbg[6], 1ull); }
 #endif
                 } else {
-                    qd = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), (unsigned)f, dest_rs(li + r, o), dest_so(so));
-                    qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), (unsigned)f, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
-                    qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), (unsigned)f, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
-                    qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), (unsigned)f, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
+                    qd = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 0, 4, xf, qa, qb, qc, qd, live, dest_o(li + r, o), f8, dest_rs(li + r, o), dest_so(so));
+                    qc = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 1, 4, xf, qd, qa, qb, qc, live, dest_o(li + r + 1, o + nf), f8, dest_rs(li + r + 1, o + nf), dest_so(so + row_bytes));
+                    qb = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 2, 4, xf, qc, qd, qa, qb, live, dest_o(li + r + 2, o + 2 * nf), f8, dest_rs(li + r + 2, o + 2 * nf), dest_so(so + 2 * row_bytes));
+                    qa = solve_elem<NL, ITERS, true, TAUP>(it_p, L, rp + 3, 4, xf, qb, qc, qd, qa, live, dest_o(li + r + 3, o + 3 * nf), f8, dest_rs(li + r + 3, o + 3 * nf), dest_so(so + 3 * row_bytes));
                 }
                 o += 4 * nf; so += 4 * row_bytes;
                 rp += 4;
             }
             li += run4;
         } else {
-            const float qn = solve_elem<NL, ITERS, false, TAUP>(it_p, L, rec3 + li, info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), (unsigned)f, dest_rs(li, o), dest_so(so));
+            const float qn = solve_elem<NL, ITERS, false, TAUP>(it_p, L, rec3 + li, info & 7, xf, qa, qb, qc, qd, live, dest_o(li, o), f8, dest_rs(li, o), dest_so(so));
             qd = qc; qc = qb; qb = qa; qa = qn;
             o += nf; so += row_bytes;
             ++li;
