@@ -403,8 +403,10 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
         const double x1 = xe_p[b1], x2 = xe_p[b2], x3 = xe_p[b3], x4 = xe_p[b4];
         const double z1 = ze_p[b1], z2 = ze_p[b2], z3 = ze_p[b3], z4 = ze_p[b4];     // all loads issued together
         // how many predecessors inside this workgroup share the element's depth (the history restarts when ze changes)
-        const bool s1 = (lane >= 1) & (z1 == z0), s2 = s1 & (lane >= 2) & (z2 == z0), s3 = s2 & (lane >= 3) & (z3 == z0),
-                   s4 = s3 & (lane >= 4) & (z4 == z0);
+        // (a predecessor at a non-finite position is no history either — its solution is NaN, and 0 x NaN in the predictor's unused
+        // terms would carry it into up to four rows behind it: scripts/exp_nan_rows.py, tests/test_gpu_edge_sizes.py)
+        const bool s1 = (lane >= 1) & (z1 == z0) & isfinite(x1), s2 = s1 & (lane >= 2) & (z2 == z0) & isfinite(x2),
+                   s3 = s2 & (lane >= 3) & (z3 == z0) & isfinite(x3), s4 = s3 & (lane >= 4) & (z4 == z0) & isfinite(x4);
         int hist = s4 ? 4 : (s3 ? 3 : (s2 ? 2 : (s1 ? 1 : 0)));
         // Lagrange weights of the extrapolation to x0 from the nodes x1 .. x_m (differences in fp64, products in fp32)
         const float t1 = (float)(x0 - x1), t2 = (float)(x0 - x2), t3 = (float)(x0 - x3), t4 = (float)(x0 - x4);

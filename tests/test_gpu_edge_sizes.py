@@ -1,5 +1,6 @@
 """GPU: size edge cases of the forward trace / matcher through the C ABI vs the C oracle —
-minimum curve (2 points), ray counts around the 8 / 64 / 512 box boundaries, one big polyline."""
+minimum curve (2 points), ray counts around the 8 / 64 / 512 box boundaries, one big polyline; and the table kernels with a
+non-finite element position inside a block of rows (the continuation's history must not carry it into the rows behind)."""
 import numpy as np
 import pytest
 
@@ -84,3 +85,57 @@ def test_more_batch_rows_than_one_grid_dimension(rtus):
         oh, ot, of = cport.match(land[row], t4, x_rx, 1e-6)
         assert np.array_equal(hit[row], oh) and np.array_equal(first[row], of) and np.array_equal(th[row], ot)
     assert hit.any(axis=1).mean() > 0.9
+
+
+@pytest.mark.parametrize("taup", [False, True])
+def test_planar_rows_behind_a_non_finite_element_position(rtus, taup):
+    """A NaN / inf element position in the middle of a block of rows (>= 8 rows per workgroup, asserted): its own row is NaN, and the
+    rows BEHIND it are what they are without it — through the plain device entry (elements as given: the continuation's history runs
+    over the bad element; round 3's kernel gave NaN for up to four rows behind it: 0 x NaN in the predictor's unused terms) and
+    through the NumPy entry (sorted: non-finite positions go last)."""
+    import torch
+    from importlib import import_module
+    from oracle import cport
+    dev = import_module("ray-tracing-ultrasound_amd.device")
+    z_if, c = [0.010, 0.025], [1483.0, 5900.0, 2330.0]
+    xs, zs = np.meshgrid(np.linspace(-0.02, 0.02, 240), np.linspace(0.004, 0.06, 220))
+    xf, zf = xs.ravel(), zs.ravel()
+    xe = (np.arange(40) - 19.5) * 0.6e-3
+    ze = np.zeros(40)
+    xe[13], xe[27], xe[39] = np.nan, np.inf, -np.inf
+    assert dev.rows_per_block(40, xf.size) >= 8
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+    ok = np.isfinite(xe)
+    ref = cport.tt_layers(z_if, c, xe[ok], ze[ok], xf, zf)
+    for tt in (dev.tt_layers_dev(z_if, c, t(xe), t(ze), t(xf), t(zf), taup=taup).cpu().numpy(),
+               rtus.travel_time_layers(z_if, c, xe, ze, xf, zf, taup=taup)):
+        assert np.isnan(tt[~ok]).all()
+        assert np.array_equal(np.isnan(tt[ok]), np.isnan(ref))
+        assert np.nanmax(np.abs(tt[ok] - ref)) < 1e-15
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_lens_rows_behind_a_non_finite_element_position(rtus, dtype):
+    """The same for the curved-lens table (its continuation runs over three previous elements)."""
+    import torch
+    from importlib import import_module
+    from oracle import cport
+    dev = import_module("ray-tracing-ultrasound_amd.device")
+    f32x = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)              # values both precisions hold exactly
+    xs, zs = np.meshgrid(np.linspace(-0.004, 0.004, 240), np.linspace(0.03, 0.07, 220))
+    xf, zf = f32x(xs.ravel()), f32x(zs.ravel())
+    xe = f32x((np.arange(40) - 19.5) * 0.3e-3)
+    ze = f32x(np.full(40, D_PLANE))
+    xe[13], xe[27] = np.nan, np.inf
+    td = getattr(torch, dtype)
+    assert dev.rows_per_block(40, xf.size, td) >= 8
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=td, device="cuda")
+    out = torch.empty((40, xf.size), dtype=td, device="cuda")
+    dev.tt_lens_rows_dev(t(xe), t(ze), t(xf), t(zf), out, params=rtus.Params())
+    tt = out.cpu().numpy().astype(np.float64)
+    ok = np.isfinite(xe)
+    rows = np.flatnonzero(ok)[[0, 11, 12, 13, 14, 15, 16, 24, 25, 26, 27, 28, 37]]          # incl. the rows right behind the bad ones
+    ref, _ = cport.tt_lens(xe[rows], ze[rows], xf, zf, -rtus.ALPHA_MAX, rtus.ALPHA_MAX)
+    assert np.isnan(tt[~ok]).all()
+    assert np.array_equal(np.isnan(tt[rows]), np.isnan(ref))
+    assert np.nanmax(np.abs(tt[rows] - ref)) < (2e-10 if dtype == "float32" else 1e-15)
