@@ -235,6 +235,8 @@ class Timed:
         torch = self.torch
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(); ev1.record()        # a torch event creates its hipEvent at the first record: 30-70 us of host time that would
+                                          # otherwise sit between t0 and the first launch (scripts/exp_bench_region.sh: 2.5 % of a K = 20 region)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()                      # same (current) stream the library launches on
