@@ -92,7 +92,7 @@ typedef const __attribute__((address_space(3))) ElemRec* RecPtr;   // a record w
 // Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
 // traversed layer (there k = 0 and w = (1 + k q^2)^(-1/2) = 1 exactly: slot 0 needs no rsqrt anywhere).
 // relative size of the Newton step at which a lane stops (and does not take it).  A HELD solve of the tau-p tier (HOLD = 2) forms its
-// second-order term from quantities good to ~1 % (3 % at worst): its error is that fraction of (tau^2 / 8) T, so it stops at a third
+// second-order term from quantities good to ~0.1 % (3.6 % at worst): its error is that fraction of (tau^2 / 8) T, so it stops at a third
 #define RTUS_PLANAR_TAU 3e-4f
 template <int NL>
 struct Lane {
@@ -326,10 +326,11 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
             G = ((L.hic * us) * (us * us)) * L.rS3;
             if (HOLD == 1) {
                 L.dG = (G - L.G) * hold_age_rcp;                // hold_age_rcp here: 1 / (elements since L.G was formed)
-                // G is a smooth function of q (|d ln G / dq| <= 3): a step of the root of <= 0.02 per element keeps the line through the
-                // last two G within ~1 % of G over the three elements ahead, and rules out a group that straddles the extremum of G
-                // under a target (first difference ~0, second difference not)
-                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(L.dG) > 0.03f * G || fabsf(h1 - h2) > 0.02f) &&   // (lanes without a path: NaN, never true)
+                // G is a smooth function of q (|d ln G / dq| <= 3, |G'' / G| <= ~20 along the aperture): a step of the root of <= 0.02
+                // per element keeps the line through the last two G within 10 (3 x 0.02)^2 = 3.6 % of G over the three elements ahead
+                // (typically ~0.1 %), and rules out a group that straddles the extremum of G under a target (first difference ~0,
+                // second difference not).  (A separate test on the first difference of G was redundant with this one: dropped.)
+                *hold_ok = !__builtin_amdgcn_ballot_w64(fabsf(h1 - h2) > 0.02f) &&   // (lanes without a path: NaN, never true)
                            (__builtin_amdgcn_readfirstlane(R->info) & 16);            // the pitch is uniform around this group
             }
             L.G = G;
@@ -497,9 +498,11 @@ __global__ __launch_bounds__(RTUS_BLOCK, (NL <= 3 && !ITERS) ? 8 : 1) void rtus_
             // HOLD (tau-p tier).  The untaken Newton step dq = dXf / X' and the tail's second-order term G dXf^2 need X'(q) and u^3
             // only to a few per cent — dq moves the history by <= tau q, the term is <= (tau^2 / 8) T — and both drift by ~1-2 % from
             // one element to the next.  So the FIRST solve of a group of four forms them exactly (HOLD = 1: the sum for X', v_rcp_f32,
-            // u^3) and, when G moved by less than 3 % per element since it was last formed (wave-uniform test) and the pitch is uniform
-            // around the group (bit 4 of the record: the extrapolation runs along the element index), the other three reuse them (HOLD = 2: eleven fp32 instructions fewer per solve); otherwise they run as before (HOLD = 0: Newton-updated
-            // reciprocal).  Error of the held term: <= ~10 % of (tau^2 / 8) T = 3e-11 T at the stopping threshold, 1e-15 T typically.
+            // u^3) and, where the root moves by <= 0.02 per element (wave-uniform test: |d ln G / dq| <= 3 and its curvature bound the
+            // line through the last two G to within ~3.6 % of G over three elements) and the pitch is uniform around the group (bit 4
+            // of the record: the line runs along the element index), the other three reuse them (HOLD = 2: eleven fp32 instructions
+            // fewer per solve, stopping at tau / 3); otherwise they form their own (HOLD = 0).  Error of the held term: <= 3.6 % of
+            // ((tau / 3)^2 / 8) T = 4.5e-11 T at the stopping threshold, 1e-15 T typically.
             // A row's bits stay a function of the table (the groups start where the four-history run starts: a function of the
             // aperture and of the rows per block).
             bool held = false;                              // L.G is one element old (else: four)
