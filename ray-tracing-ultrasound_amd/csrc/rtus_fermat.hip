@@ -89,11 +89,12 @@ struct __attribute__((aligned(16))) ElemRec {
 
 typedef const __attribute__((address_space(3))) ElemRec* RecPtr;   // a record where it lives: LDS (ds_read at a register + immediate offset)
 
+// Relative size of the Newton step at which a lane stops (and does not take it).  A HELD solve of the tau-p tier (HOLD = 2) forms its
+// second-order term from quantities good to ~0.1 % (3.6 % at worst): its error is that fraction of (tau^2 / 8) T, so it stops at a third.
+#define RTUS_PLANAR_TAU 3e-4f
+
 // Per-lane solver state: the layer table of this lane's target, PERMUTED so that slot 0 is the lane's fastest
 // traversed layer (there k = 0 and w = (1 + k q^2)^(-1/2) = 1 exactly: slot 0 needs no rsqrt anywhere).
-// relative size of the Newton step at which a lane stops (and does not take it).  A HELD solve of the tau-p tier (HOLD = 2) forms its
-// second-order term from quantities good to ~0.1 % (3.6 % at worst): its error is that fraction of (tau^2 / 8) T, so it stops at a third
-#define RTUS_PLANAR_TAU 3e-4f
 template <int NL>
 struct Lane {
     double hr0, hc0, hr[NL], kk[NL], hc[NL], inv_cm;       // slots 1 .. NL-1 of the arrays are used
@@ -193,8 +194,8 @@ __device__ __forceinline__ float solve_elem(uint8_t* __restrict__ iters, Lane<NL
     // the stopping threshold.  Lanes whose target is not below the element carry garbage
     // through the arithmetic (never a step: tau = +inf) and get NaN at the store.
     // FAST (a four-history run) works on the SIGNED problem X(qs) = xf - xe — X(q) = q S1(q^2) is odd, the predictor's history is
-    // signed anyway — so the common path has no |.| to materialise and no sign to put back (a v_and and a v_bfi per solve); only
-    // the rare second-evaluation branch goes back to q >= 0, where the lower-bound clamp lives.
+    // signed anyway — so the common path has no |.| to materialise and no sign to put back (a v_and and a v_bfi per solve); the
+    // rare second-evaluation branch stays signed too and clamps to the signed lower bound (one v_med3_f32).
     float Xf = FAST ? (float)dxs : (float)X;
     double Xt = FAST ? dxs : X;                             // the reach that pairs with q in the tail (same sign as q)
     float y[NL], dq = 0.0f, dXf = 0.0f;                     // dq: the (small, untaken) Newton step of the last evaluation, dXf its residual
