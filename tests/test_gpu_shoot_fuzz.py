@@ -73,3 +73,12 @@ def test_fuzz_root_finding_solve_vs_oracle(rtus):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK: 45 trials" in r.stdout
+
+
+def test_planar_exact_boundary_cases_vs_oracle(rtus):
+    """scripts/exp_planar_exact_cases.py: what a random fuzz never draws — targets and elements EXACTLY on interface depths, targets
+    exactly below elements (dx = 0) and at the elements' own x, a whole table above its aperture, half of one — on tables with >= 8 rows
+    per workgroup, both tiers, the plain and the sorted entry: identical NaN masks, |dt| <= 2e-11 t (tau-p tier: 6e-11 t)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp_planar_exact_cases.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "FAILURES: 0" in r.stdout
