@@ -82,3 +82,12 @@ def test_planar_exact_boundary_cases_vs_oracle(rtus):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp_planar_exact_cases.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAILURES: 0" in r.stdout
+
+
+def test_lens_exact_symmetry_cases_vs_oracle(rtus):
+    """scripts/exp_lens_exact_cases.py: the curved-lens tables on a mirror-symmetric aperture and grid with an on-axis element and an
+    on-axis target column (x = 0 exactly), target columns at the elements' own x, every position three times, and a symmetric window
+    through the focus — fp64 <= 1e-15 s, fp32 <= 2e-10 s against the global-minimum oracle, >= 8 rows per workgroup."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp_lens_exact_cases.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "FAILURES: 0" in r.stdout
