@@ -602,6 +602,9 @@ int rtus_rows_per_block(long long n_rows_total, int n_f, int n_batch, int elem_b
     return eb;
 }
 
+#ifndef RTUS_PLANAR_SHAPE_LDS
+#define RTUS_PLANAR_SHAPE_LDS 0u   // experiment builds: unused LDS per workgroup = fewer workgroups per CU (see launch_layers)
+#endif
 static hipError_t launch_layers(const double* z_if, const double* c, int n_if, const double* xe, const double* ze, int n_e,
                                 const double* xf, const double* zf, int n_f, double* tt, uint8_t* iters, int n_batch,
                                 long long e_stride, long long f_stride, long long t_stride, int row0, long long n_rows_total,
@@ -633,16 +636,11 @@ static hipError_t launch_layers(const double* z_if, const double* c, int n_if, c
     const dim3 grid(a.gx, a.gy, n_batch), block(RTUS_BLOCK);
 #endif
     const bool taup = (flags & RTUS_TT_TAUP_TAIL) != 0;
-    // Workgroups per CU.  The registers allow 8 (the 64-VGPR kernels: up to three layers), and a launch of 16 per CU then runs as two
-    // rounds that start and end together — every wave of a SIMD in the same phase of its block (cold start / four-history run) at the
-    // same time.  Asking for 24 KB of LDS the kernel never touches caps it at SIX per CU: the rounds overlap, the launch is 3.5 %
-    // shorter on BASELINE configs[2] (7: -2.5 %, 5: +0.8 %, 4: +1.4 %, 3: +6.7 %; a launch of one round: +0.6 %, so only from two
-    // rounds on).  (4096 = 16 x the 256 CUs of the one part this library is written for.)
-#ifdef RTUS_EXP_PERSIST                                      // (the persistent grid is the experiment with ALL eight slots per SIMD taken)
-    const unsigned lds = 0u;
-#else
-    const unsigned lds = (n_if + 1 <= 3 && !iters && items >= 4096) ? 24u * 1024u : 0u;
-#endif
+    // Workgroups per CU: what the registers allow (8 for the 64-VGPR kernels).  Capping a launch of two rounds or more BELOW that with
+    // LDS the kernel never touches (-DRTUS_PLANAR_SHAPE_LDS=bytes, experiment builds) was worth -3.5 % at six per CU while the kernel
+    // still parked set-up values in scratch and loaded extra header words (start-up that nothing overlapped when every wave of a SIMD
+    // began at once); on the kernel as it is now six per CU is 0.5 - 1.6 % SLOWER than eight and seven is even: no shaping.
+    const unsigned lds = (n_if + 1 <= 3 && !iters && items >= 4096) ? RTUS_PLANAR_SHAPE_LDS : 0u;
     switch (n_if + 1) {
 #define RTUS_CASE(NL) case NL: if (iters) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, true, false, false>), grid, block, lds, s, a); \
                                else if (row_of && taup) hipLaunchKernelGGL((rtus_tt_layers_kernel<NL, false, true, true>), grid, block, lds, s, a); \

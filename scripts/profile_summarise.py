@@ -167,14 +167,14 @@ if os.path.isdir(os.path.join(src, "sq_persist")):
         clk = clock
         ns = cp["_duration_ns:SQ_WAVE_CYCLES"]
         valu["cfg3_planar_persistent_grid_experiment"] = {
-            "build": "-DRTUS_EXP_PERSIST: 2,048 workgroups (8 per CU, every wave slot taken from start to end), each takes work items w, w + 2048, ... (the product launches 4,096 workgroups and, since late round 4, caps itself at SIX per CU through 24 KB of unused LDS: rounds that overlap instead of two that start and end together)",
+            "build": "-DRTUS_EXP_PERSIST: 2,048 workgroups (8 per CU, every wave slot taken from start to end), each takes work items w, w + 2048, ... (the product launches 4,096 workgroups, two rounds of 8 per CU)",
             "waves": int(cp["SQ_WAVES"]), "insts_valu": int(cp["SQ_INSTS_VALU"]),
             "wave_life_us_mean": round(4 * cp["SQ_WAVE_CYCLES"] / cp["SQ_WAVES"] / (clk * 1e3), 2),
             "wave_slots_occupied_frac_of_kernel": round((4 * cp["SQ_WAVE_CYCLES"] / (clk * 1e9)) / (8 * 1024 * ns * 1e-9), 3),
             "profiled_launch_us": round(ns / 1e3, 1),
             "product_profiled_launch_us": valu["cfg3_planar"]["profiled_launch_us"],
             "product_wave_slots_occupied_frac_of_kernel": valu["cfg3_planar"]["wave_slots_occupied_frac_of_kernel"],
-            "reading": "full wave slots do not shorten the launch — the product with a quarter of its slots deliberately empty is faster (launch shapes of 3 .. 8 workgroups per CU: rtus_fermat.hip launch_layers); what costs time is workgroups starting and ending TOGETHER (start-up latency nothing overlaps), not residency",
+            "reading": "full wave slots do not shorten the launch (launch shapes of 3 .. 8 workgroups per CU were measured too: rtus_fermat.hip launch_layers, DESIGN.md section 4): the kernel is bound by VALU issue, not by residency",
         }
         write_counters(os.path.join(dst, f"{tag}_pmc_sq_cfg3_persist.csv"), tp, mp)
 json.dump(valu, open(os.path.join(dst, f"valu_{tag}.json"), "w"), indent=1)
