@@ -295,8 +295,10 @@ int rtus_sweep(const rtus_lens *lens, const double *geoms, int n_geom,
 /* Accuracy tier of the planar solver (flags of the *_ex entries, rtus_tt_layers_rows_dev, rtus_tt_layers_sorted_dev).  0: the travel time from an fp64
  * evaluation at the Newton iterate + its second-order Fermat expansion in an fp64 residual: <= 1e-13 relative (measured 3e-18 s
  * on BASELINE config 3).  RTUS_TT_TAUP_TAIL: from the tau-p form T = p X + sum (h_i/c_i) cos(theta_i), stationary in p, with the
- * second-order term from the fp32 residual: four fp64 instructions fewer per solve, <= 6e-11 relative (~2e-15 s) at worst,
- * ~3e-14 typically — six orders inside the 1e-9 s bar of the north-star. */
+ * second-order term from the fp32 residual (and, on a uniform pitch where the solution moves slowly from element to element, with
+ * the term's coefficient carried over groups of four elements): <= 6e-11 relative (~2e-15 s) at worst, ~3e-14 typically — six orders
+ * inside the 1e-9 s bar of the north-star.  (Held to that bar on random, coarse and irregular apertures by scripts/fuzz_layers.py
+ * --taup; round 3's version of this tier exceeded it — 2.8e-10 relative — on coarse random pitches.) */
 #define RTUS_TT_TAUP_TAIL 0x1u
 
 int rtus_tt_layers_dev(const double *z_if, const double *c, int n_if,
